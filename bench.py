@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- car-steps/s of the 24-hour resample (src/resampling.jl + the saveresults
+histogram) on N MI355X, with the HBM roofline of the hourly sampler kernel and the CPU
+restatement timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full T=24 hour resample of every car (tables, CDF and the post-IVP initial
+state already resident in HBM), through the zone x hour count tensor -- and, for N > 1, through
+the single RCCL all-reduce of that tensor.  Workload at N = 1: synthetic dense Z = 4,096 zones,
+1,000 cars/zone (BASELINE.json configs[2], the configuration the metric is quoted on).  For
+N > 1 the cars per GPU stay fixed (weak scaling): Z = 4,096, 1,000*N cars/zone sharded by car.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TABLE_SEED = 0x5EED7AB1E
+SIM_SEED = 0x5EEDCA125
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
+    """The faithful three-pass restatement of src/resampling.jl (oracle, single thread) on a
+    bounded sample: the first `n_cars` cars, 24 h, starting from their post-IVP zones; its counts
+    are checked against the HIP path on the same cars."""
+    import numpy as np
+    from oracle import oracle as O
+
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)        # reference layout, Z*Z*T*8 bytes on the host
+    zones = sampler.get_state()[:n_cars].copy()
+    # calibrate the sample to the time budget on a small slice first
+    probe = min(256, n_cars)
+    st, tr = O.initializestates(probe, 1, T)
+    st[:, 0] = zones[:probe]
+    t0 = time.perf_counter()
+    O.resampling(st, tr, probe, Z, p_drive, p_dest, None, None, SIM_SEED, car_offset=0)
+    per_car = (time.perf_counter() - t0) / probe
+    n = int(max(probe, min(n_cars, time_budget_s / max(per_car, 1e-9))))
+    st, tr = O.initializestates(n, 1, T)
+    st[:, 0] = zones[:n]
+    t0 = time.perf_counter()
+    O.resampling(st, tr, n, Z, p_drive, p_dest, None, None, SIM_SEED, car_offset=0)
+    dt = time.perf_counter() - t0
+    pk, dr, _ = O.histogram(Z, st, tr)
+    # the same cars through the HIP path
+    C_total, cpz, begin, count = sampler.C_total, sampler.cars_per_zone, sampler.car_begin, sampler.car_count
+    full = sampler.get_state()
+    sampler.init_states(C_total, cpz, 0, n)
+    sampler.set_state(zones[:n])
+    r = sampler.resample(SIM_SEED)
+    ok = bool(np.array_equal(r["parking"], pk.astype(np.int64)) and np.array_equal(r["driving"], dr.astype(np.int64)))
+    sampler.init_states(C_total, cpz, begin, count)
+    sampler.set_state(full)
+    return {"value": n * T / dt, "unit": "car-steps/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} cars x {T} h of the same workload (faithful three-pass restatement of "
+                      f"src/resampling.jl, strided p_dest row gather + sum + linear walk), {dt:.1f} s",
+            "counts_match_gpu": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--zones", type=int, default=4096)
+    ap.add_argument("--cars-per-zone", type=int, default=1000, help="per GPU (weak scaling)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import carparkingmaps_amd as cpm
+    from carparkingmaps_amd.distributed import ShardedSampler
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    Z, T = args.zones, 24
+    cpz = args.cars_per_zone * world
+    C = Z * cpz
+    ss = ShardedSampler(Z, T, rank=rank, world_size=world, device=local_rank)
+    s = ss.s
+    s.set_kernel(args.kernel)
+    s.synth_tables(TABLE_SEED)
+    begin, count = ss.init_states(C, cpz)
+    s.solve_ivp_async(SIM_SEED)          # 23 untimed burn-in steps (main.jl:91-92)
+    s.sync()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ss.resample_allreduce(SIM_SEED)
+    barrier()
+    s.set_profile(True)                   # hipEvents around every hourly kernel, on its own stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ss.resample_allreduce(SIM_SEED)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = s.last_kernel_ms()
+    s.set_profile(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    parking, driving, _ = cpm.distributed.split_counts(ss.counts, Z, T)
+    assert (parking.sum(axis=0) == C).all(), "every hour must hold all C cars"
+
+    if rank == 0:
+        car_steps = C * T
+        alg_bytes = s.algorithmic_bytes_per_hour()
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "car-steps/sec at Z=4,096, 1k cars/zone; 1/2/4/8 MI355X + %HBM roofline",
+            "value": car_steps * args.steps / dt,
+            "unit": "car-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
+                                   f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
+                       "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
+                       "kernel": {0: "auto", 1: "car", 2: "zone_lds"}[args.kernel],
+                       "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 1}]",
+                       "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
+                       "device": cpm.device_info(local_rank)["name"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hourly sampler launch", "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(s, Z, T, min(count, 65536), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ss.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

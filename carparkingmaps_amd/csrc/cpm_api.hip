@@ -1,0 +1,659 @@
+// cpm_api.hip -- host side of libcpm_hip.so: context, device memory, launches and the
+// C ABI declared in include/cpm.h.  gfx950 only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cpm.h"
+#include "cpm_kernels.h"
+#include "cpm_tables.h"
+#include "cpm_zone_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                            \
+    } while (0)
+
+#define CTX_TRY(ctx)                                                 \
+    if (!(ctx)) return fail(CPM_ERR_ARG, "null context");            \
+    HIP_TRY(hipSetDevice((ctx)->device))
+
+template <typename T>
+void dfree(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+inline unsigned nblk(int64_t n, int b) { return static_cast<unsigned>((n + b - 1) / b); }
+
+}  // namespace
+
+struct cpm_ctx {
+    int64_t Z = 0, T = 0;
+    int Zp = 0;
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // tables
+    double *d_pdrive = nullptr;  // [T][Z]
+    double *d_cdf = nullptr;     // [T][Z][Zp]
+    double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
+    double *d_dist = nullptr;    // [Z][Z]
+    bool have_pdrive = false, have_cdf = false, have_dm = false;
+    // cars
+    int64_t C_total = 0, cpz = 0, car_begin = 0, n = 0;
+    uint32_t *d_zone0 = nullptr;  // [n] current zones
+    uint32_t *d_ztmp = nullptr;   // [n] ping-pong for the IVP
+    uint32_t *d_rec = nullptr;    // [T][n]
+    int64_t rec_cap = 0;
+    bool have_state = false;
+    // results
+    int64_t *d_counts = nullptr;  // [2*T*Z + 1]
+    int *d_err = nullptr;
+    // zone-bucket path
+    cpm::ZoneWork zw;
+    // options
+    int kernel = CPM_KERNEL_AUTO;
+    bool profile = false;
+    std::vector<hipEvent_t> ev;  // 2 per hourly launch
+    int n_prof = 0;
+};
+
+namespace {
+
+int32_t ensure_cars(cpm_ctx *c, int64_t n)
+{
+    if (n == c->n && c->d_zone0) return CPM_OK;
+    dfree(c->d_zone0);
+    dfree(c->d_ztmp);
+    dfree(c->d_rec);
+    c->rec_cap = 0;
+    c->n = n;
+    if (n > 0) {
+        HIP_TRY(hipMalloc(&c->d_zone0, sizeof(uint32_t) * n));
+        HIP_TRY(hipMalloc(&c->d_ztmp, sizeof(uint32_t) * n));
+    }
+    return CPM_OK;
+}
+
+int32_t ensure_rec(cpm_ctx *c)
+{
+    int64_t need = c->n * c->T;
+    if (c->rec_cap >= need && c->d_rec) return CPM_OK;
+    dfree(c->d_rec);
+    HIP_TRY(hipMalloc(&c->d_rec, sizeof(uint32_t) * std::max<int64_t>(need, 1)));
+    c->rec_cap = need;
+    return CPM_OK;
+}
+
+int32_t check_err_flag(cpm_ctx *c, const char *what, int32_t code)
+{
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h) {
+        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        return fail(code, "%s", what);
+    }
+    return CPM_OK;
+}
+
+// p (device, reference layout Z x Z x T) -> canonical CDF
+int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
+{
+    size_t cdf_elems = static_cast<size_t>(c->T) * c->Z * c->Zp;
+    if (!c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * cdf_elems));
+    dim3 grid(nblk(c->Z, cpm::kCdfTile), static_cast<unsigned>(c->T));
+    hipLaunchKernelGGL(cpm::k_build_cdf, grid, dim3(cpm::kCdfTile), 0, c->stream, d_p, c->d_cdf,
+                       static_cast<int>(c->Z), c->Zp, c->d_err);
+    HIP_TRY(hipGetLastError());
+    c->have_cdf = false;
+    int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)",
+                                CPM_ERR_TABLE);
+    if (rc != CPM_OK) return rc;
+    c->have_cdf = true;
+    c->zw.tables_dirty = true;
+    return CPM_OK;
+}
+
+int pick_kernel(const cpm_ctx *c)
+{
+    if (c->kernel != CPM_KERNEL_AUTO) return c->kernel;
+    return CPM_KERNEL_CAR;
+}
+
+constexpr int kMaxProf = 8192;
+
+void prof_begin(cpm_ctx *c)
+{
+    if (!c->profile || c->n_prof >= kMaxProf) return;
+    size_t k = static_cast<size_t>(c->n_prof) * 2;
+    while (c->ev.size() < k + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->ev.push_back(e);
+    }
+    (void)hipEventRecord(c->ev[k], c->stream);
+}
+
+void prof_end(cpm_ctx *c)
+{
+    if (!c->profile || c->n_prof >= kMaxProf) return;
+    size_t k = static_cast<size_t>(c->n_prof) * 2;
+    if (c->ev.size() < k + 2) return;
+    (void)hipEventRecord(c->ev[k + 1], c->stream);
+    c->n_prof++;
+}
+
+// one hourly step of the one-thread-per-car kernel
+int32_t launch_step_car(cpm_ctx *c, const uint32_t *zin, uint32_t *out, int t, uint32_t step, uint64_t seed,
+                        bool travel, unsigned long long *tt_sum)
+{
+    const double *pd = c->d_pdrive + static_cast<size_t>(t) * c->Z;
+    const double *cdf = c->d_cdf + static_cast<size_t>(t) * c->Z * c->Zp;
+    dim3 grid(nblk(c->n, 256)), block(256);
+    if (travel)
+        hipLaunchKernelGGL(cpm::k_step_car<true>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
+                           c->Zp, c->n, c->car_begin, step, seed, c->d_dm, static_cast<int>(c->T), t, tt_sum);
+    else
+        hipLaunchKernelGGL(cpm::k_step_car<false>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
+                           c->Zp, c->n, c->car_begin, step, seed, nullptr, static_cast<int>(c->T), t, nullptr);
+    HIP_TRY(hipGetLastError());
+    return CPM_OK;
+}
+
+int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
+{
+    unsigned long long *parking = reinterpret_cast<unsigned long long *>(d_counts);
+    unsigned long long *driving = parking + c->T * c->Z;
+    size_t lds = sizeof(uint32_t) * 2 * c->Z;
+    if (lds <= 160 * 1024) {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_histogram),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        // enough chunks to fill the chip, few enough that the flush (2*Z atomics per block) stays small
+        int64_t chunks = std::max<int64_t>(1, std::min<int64_t>((c->n + 16383) / 16384, 2 * c->cu_count / std::max<int64_t>(c->T / 4, 1) + 8));
+        int64_t chunk = (c->n + chunks - 1) / chunks;
+        dim3 grid(static_cast<unsigned>(chunks), static_cast<unsigned>(c->T));
+        hipLaunchKernelGGL(cpm::k_histogram, grid, dim3(1024), lds, c->stream, c->d_zone0, c->d_rec, c->n,
+                           static_cast<int>(c->Z), parking, driving, chunk);
+    } else {
+        dim3 grid(nblk(c->n, 256), static_cast<unsigned>(c->T));
+        hipLaunchKernelGGL(cpm::k_histogram_global, grid, dim3(256), 0, c->stream, c->d_zone0, c->d_rec, c->n,
+                           static_cast<int>(c->Z), parking, driving);
+    }
+    HIP_TRY(hipGetLastError());
+    return CPM_OK;
+}
+
+int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_counts)
+{
+    if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "resample: p_drive / p_dest not set");
+    if (!c->have_state) return fail(CPM_ERR_STATE, "resample: no car state (cpm_init_states / cpm_set_state)");
+    bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
+    if (travel && !c->have_dm) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
+    size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 1);
+    HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
+    if (c->n == 0) return CPM_OK;
+    unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_LDS) {
+        return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
+                                  d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                                  g_last_error);
+    }
+    int32_t rc = ensure_rec(c);
+    if (rc != CPM_OK) return rc;
+    for (int t = 0; t < c->T; ++t) {
+        const uint32_t *zin = (t == 0) ? c->d_zone0 : c->d_rec + static_cast<size_t>(t - 1) * c->n;
+        uint32_t *out = c->d_rec + static_cast<size_t>(t) * c->n;
+        prof_begin(c);
+        rc = launch_step_car(c, zin, out, t, static_cast<uint32_t>(c->T - 1 + t), seed, travel, tt_sum);
+        prof_end(c);
+        if (rc != CPM_OK) return rc;
+    }
+    return launch_histogram(c, d_counts);
+}
+
+int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
+{
+    if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "solve_ivp: p_drive / p_dest not set");
+    if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
+    if (c->n == 0) return CPM_OK;
+    // src/solveinitialvalueproblem.jl:8 : t = 1:(T-1), state update unconditional (:53)
+    for (int t = 0; t < c->T - 1; ++t) {
+        int32_t rc = launch_step_car(c, c->d_zone0, c->d_ztmp, t, static_cast<uint32_t>(t), seed, false, nullptr);
+        if (rc != CPM_OK) return rc;
+        std::swap(c->d_zone0, c->d_ztmp);  // flag bit is masked off by every reader
+    }
+    return CPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cpm_last_error(void) { return g_last_error.c_str(); }
+
+int32_t cpm_version(void) { return 100; }
+
+int32_t cpm_device_count(int32_t *n_out)
+{
+    if (!n_out) return fail(CPM_ERR_ARG, "null n_out");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    *n_out = n;
+    return CPM_OK;
+}
+
+int32_t cpm_device_info(int32_t device_id, char *name, int32_t len, int32_t *cu_count, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device_id));
+    if (name && len > 0) {
+        std::snprintf(name, static_cast<size_t>(len), "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(p.totalGlobalMem);
+    return CPM_OK;
+}
+
+int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
+{
+    if (!ctx_out) return fail(CPM_ERR_ARG, "null ctx_out");
+    *ctx_out = nullptr;
+    if (Z < 1 || Z > (int64_t(1) << 24)) return fail(CPM_ERR_ARG, "number_zones %lld out of range", (long long)Z);
+    if (T < 1 || T > 4096) return fail(CPM_ERR_ARG, "T %lld out of range", (long long)T);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(CPM_ERR_HIP, "no HIP device: this library has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return fail(CPM_ERR_ARG, "device %d of %d", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    cpm_ctx *c = new (std::nothrow) cpm_ctx();
+    if (!c) return fail(CPM_ERR_NOMEM, "host allocation failed");
+    c->Z = Z;
+    c->T = T;
+    c->Zp = static_cast<int>((Z + 15) / 16 * 16);
+    c->device = device_id;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->cu_count = p.multiProcessorCount;
+    if (c->cu_count <= 0) c->cu_count = 256;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 1));
+    if (e != hipSuccess) {
+        cpm_destroy(c);
+        return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *ctx_out = c;
+    return CPM_OK;
+}
+
+int32_t cpm_destroy(cpm_ctx *c)
+{
+    if (!c) return CPM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dfree(c->d_pdrive);
+    dfree(c->d_cdf);
+    dfree(c->d_dm);
+    dfree(c->d_dist);
+    dfree(c->d_zone0);
+    dfree(c->d_ztmp);
+    dfree(c->d_rec);
+    dfree(c->d_counts);
+    dfree(c->d_err);
+    c->zw.release();
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return CPM_OK;
+}
+
+int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
+{
+    CTX_TRY(c);
+    switch (option) {
+    case CPM_OPT_KERNEL:
+        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_LDS) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        c->kernel = static_cast<int>(value);
+        return CPM_OK;
+    case CPM_OPT_PROFILE:
+        c->profile = value != 0;
+        c->n_prof = 0;  // (re)start the record; hourly launches append until read or reset
+        return CPM_OK;
+    default:
+        return fail(CPM_ERR_ARG, "unknown option %d", option);
+    }
+}
+
+int32_t cpm_set_stream(cpm_ctx *c, void *hip_stream)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return CPM_OK;
+}
+
+int32_t cpm_sync(cpm_ctx *c)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CPM_OK;
+}
+
+// ------------------------------------------------------------------ tables
+
+int32_t cpm_set_p_drive(cpm_ctx *c, const double *p_drive)
+{
+    CTX_TRY(c);
+    if (!p_drive) return fail(CPM_ERR_ARG, "null p_drive");
+    size_t bytes = sizeof(double) * c->Z * c->T;
+    if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
+    HIP_TRY(hipMemcpyAsync(c->d_pdrive, p_drive, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_pdrive = true;
+    return CPM_OK;
+}
+
+int32_t cpm_set_p_dest(cpm_ctx *c, const double *p_dest)
+{
+    CTX_TRY(c);
+    if (!p_dest) return fail(CPM_ERR_ARG, "null p_dest");
+    size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
+    double *d_p = nullptr;
+    HIP_TRY(hipMalloc(&d_p, bytes));
+    hipError_t e = hipMemcpyAsync(d_p, p_dest, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        dfree(d_p);
+        return fail(CPM_ERR_HIP, "upload p_dest: %s", hipGetErrorString(e));
+    }
+    int32_t rc = build_cdf_from_device(c, d_p);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(d_p);
+    return rc;
+}
+
+int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *dist)
+{
+    CTX_TRY(c);
+    if (!datamatrix || !dist) return fail(CPM_ERR_ARG, "null datamatrix / dist");
+    size_t bytes = sizeof(double) * c->Z * c->Z * c->T * 2;
+    size_t dbytes = sizeof(double) * c->Z * c->Z;
+    if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, bytes));
+    if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
+    HIP_TRY(hipMemcpyAsync(c->d_dm, datamatrix, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_dm = true;
+    return CPM_OK;
+}
+
+int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive, double *out)
+{
+    CTX_TRY(c);
+    if (!c->have_dm) return fail(CPM_ERR_STATE, "build_p_drive: cpm_set_datamatrix first");
+    size_t bytes = sizeof(double) * c->Z * c->T;
+    if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
+    double *d_ms = nullptr;
+    HIP_TRY(hipMalloc(&d_ms, bytes));
+    dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
+    hipLaunchKernelGGL(cpm::k_pdrive_mean, grid, dim3(64), 0, c->stream, c->d_dm, c->d_dist, d_ms, static_cast<int>(c->Z));
+    hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64)), dim3(64), 0, c->stream, d_ms, c->d_pdrive,
+                       static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d_ms);
+    if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_drive: %s", hipGetErrorString(e));
+    c->have_pdrive = true;
+    return CPM_OK;
+}
+
+int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double *out)
+{
+    CTX_TRY(c);
+    if (!c->have_dm) return fail(CPM_ERR_STATE, "build_p_dest: cpm_set_datamatrix first");
+    size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
+    double *d_p = nullptr;
+    HIP_TRY(hipMalloc(&d_p, bytes));
+    dim3 g1(nblk(c->Z, 64), static_cast<unsigned>(c->Z));
+    hipLaunchKernelGGL(cpm::k_pdest_weights, g1, dim3(64), 0, c->stream, c->d_dm, d_p, static_cast<int>(c->Z),
+                       static_cast<int>(c->T), e_dest, e_is_integer);
+    dim3 g2(nblk(c->Z, 64), static_cast<unsigned>(c->T));
+    hipLaunchKernelGGL(cpm::k_pdest_normalise, g2, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_p, bytes, hipMemcpyDeviceToHost, c->stream);
+    int32_t rc = CPM_OK;
+    if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));
+    if (rc == CPM_OK) rc = build_cdf_from_device(c, d_p);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(d_p);
+    return rc;
+}
+
+int32_t cpm_get_p_drive(cpm_ctx *c, double *out)
+{
+    CTX_TRY(c);
+    if (!out) return fail(CPM_ERR_ARG, "null out");
+    if (!c->have_pdrive) return fail(CPM_ERR_STATE, "p_drive not set");
+    HIP_TRY(hipMemcpyAsync(out, c->d_pdrive, sizeof(double) * c->Z * c->T, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CPM_OK;
+}
+
+int32_t cpm_get_cdf_row(cpm_ctx *c, int64_t origin1, int64_t hour1, double *out)
+{
+    CTX_TRY(c);
+    if (!out) return fail(CPM_ERR_ARG, "null out");
+    if (!c->have_cdf) return fail(CPM_ERR_STATE, "p_dest not set");
+    if (origin1 < 1 || origin1 > c->Z || hour1 < 1 || hour1 > c->T) return fail(CPM_ERR_ARG, "row index out of range");
+    const double *src = c->d_cdf + (static_cast<size_t>(hour1 - 1) * c->Z + (origin1 - 1)) * c->Zp;
+    HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * c->Z, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CPM_OK;
+}
+
+int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
+{
+    CTX_TRY(c);
+    size_t pd_bytes = sizeof(double) * c->Z * c->T;
+    if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, pd_bytes));
+    hipLaunchKernelGGL(cpm::k_synth_p_drive, dim3(nblk(c->Z * c->T, 256)), dim3(256), 0, c->stream, c->d_pdrive,
+                       static_cast<int>(c->Z), static_cast<int>(c->T), table_seed);
+    HIP_TRY(hipGetLastError());
+    c->have_pdrive = true;
+    double *d_p = nullptr;
+    HIP_TRY(hipMalloc(&d_p, sizeof(double) * c->Z * c->Z * c->T));
+    dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
+    hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z), table_seed);
+    int32_t rc = CPM_OK;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "synth_tables: %s", hipGetErrorString(e));
+    if (rc == CPM_OK) rc = build_cdf_from_device(c, d_p);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(d_p);
+    return rc;
+}
+
+// ------------------------------------------------------------------ cars
+
+int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int64_t car_begin, int64_t car_count)
+{
+    CTX_TRY(c);
+    if (C_total < 0 || cars_per_zone < 1 || car_begin < 0 || car_count < 0 || car_begin + car_count > C_total)
+        return fail(CPM_ERR_ARG, "init_states: bad car range [%lld, +%lld) of %lld", (long long)car_begin,
+                    (long long)car_count, (long long)C_total);
+    if (C_total > 0 && (C_total - 1) / cars_per_zone >= c->Z)
+        return fail(CPM_ERR_ARG, "init_states: C = %lld cars at %lld per zone exceed %lld zones", (long long)C_total,
+                    (long long)cars_per_zone, (long long)c->Z);
+    int32_t rc = ensure_cars(c, car_count);
+    if (rc != CPM_OK) return rc;
+    c->C_total = C_total;
+    c->cpz = cars_per_zone;
+    c->car_begin = car_begin;
+    if (car_count > 0) {
+        hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, car_begin,
+                           car_count, cars_per_zone);
+        HIP_TRY(hipGetLastError());
+    }
+    c->have_state = true;
+    return CPM_OK;
+}
+
+int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
+{
+    CTX_TRY(c);
+    if (!c->have_state) return fail(CPM_ERR_STATE, "set_state: cpm_init_states first (defines the car range)");
+    if (c->n == 0) return CPM_OK;
+    if (!zones) return fail(CPM_ERR_ARG, "null zones");
+    int64_t *d_z = nullptr;
+    HIP_TRY(hipMalloc(&d_z, sizeof(int64_t) * c->n));
+    hipError_t e = hipMemcpyAsync(d_z, zones, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cpm::k_zones_from_i64, dim3(nblk(c->n, 256)), dim3(256), 0, c->stream, c->d_zone0, d_z, c->n,
+                           c->Z, c->d_err);
+        e = hipGetLastError();
+    }
+    int32_t rc = (e == hipSuccess) ? check_err_flag(c, "set_state: zone id outside 1..number_zones", CPM_ERR_ARG)
+                                   : fail(CPM_ERR_HIP, "set_state: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dfree(d_z);
+    return rc;
+}
+
+int32_t cpm_get_state(cpm_ctx *c, int64_t *zones_out)
+{
+    CTX_TRY(c);
+    if (!c->have_state) return fail(CPM_ERR_STATE, "get_state: no car state");
+    if (c->n == 0) return CPM_OK;
+    if (!zones_out) return fail(CPM_ERR_ARG, "null zones_out");
+    int64_t *d_z = nullptr;
+    HIP_TRY(hipMalloc(&d_z, sizeof(int64_t) * c->n));
+    hipLaunchKernelGGL(cpm::k_zones_to_i64, dim3(nblk(c->n, 256)), dim3(256), 0, c->stream, d_z, c->d_zone0, c->n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(zones_out, d_z, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d_z);
+    if (e != hipSuccess) return fail(CPM_ERR_HIP, "get_state: %s", hipGetErrorString(e));
+    return CPM_OK;
+}
+
+int32_t cpm_solve_ivp_async(cpm_ctx *c, uint64_t seed)
+{
+    CTX_TRY(c);
+    return ivp_enqueue(c, seed);
+}
+
+int32_t cpm_solve_ivp(cpm_ctx *c, uint64_t seed, int64_t *initial_state_out)
+{
+    CTX_TRY(c);
+    int32_t rc = ivp_enqueue(c, seed);
+    if (rc != CPM_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (initial_state_out) return cpm_get_state(c, initial_state_out);
+    return CPM_OK;
+}
+
+int32_t cpm_resample_dev(cpm_ctx *c, uint64_t seed, uint32_t flags, void *d_counts)
+{
+    CTX_TRY(c);
+    if (!d_counts) return fail(CPM_ERR_ARG, "null d_counts");
+    return resample_enqueue(c, seed, flags, static_cast<int64_t *>(d_counts));
+}
+
+int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking, int64_t *driving,
+                     int64_t *sum_tt_q16, int64_t *state_out, double *trans_out)
+{
+    CTX_TRY(c);
+    if (!parking || !driving) return fail(CPM_ERR_ARG, "null count outputs");
+    bool compat = state_out || trans_out;
+    int saved_kernel = c->kernel;
+    if (compat) c->kernel = CPM_KERNEL_CAR;  // the per-hour records of every car are kept by this path
+    int32_t rc = resample_enqueue(c, seed, flags, c->d_counts);
+    c->kernel = saved_kernel;
+    if (rc != CPM_OK) return rc;
+    size_t zt = static_cast<size_t>(c->Z * c->T);
+    HIP_TRY(hipMemcpyAsync(parking, c->d_counts, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(driving, c->d_counts + zt, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
+    int64_t tt = 0;
+    HIP_TRY(hipMemcpyAsync(&tt, c->d_counts + 2 * zt, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sum_tt_q16) *sum_tt_q16 = tt;
+    if (compat && c->n > 0) {
+        // one hour column at a time: state[:,t] and trans[:,t,1..4] are contiguous runs of C values
+        int64_t n = c->n;
+        char *d_cols = nullptr;
+        HIP_TRY(hipMalloc(&d_cols, static_cast<size_t>(n) * 8 * 5));
+        int64_t *d_state = reinterpret_cast<int64_t *>(d_cols);
+        double *d_f = reinterpret_cast<double *>(d_cols) + n;
+        bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
+        hipError_t e = hipSuccess;
+        for (int t = 0; t < c->T && e == hipSuccess; ++t) {
+            const uint32_t *zsrc = (t == 0) ? c->d_zone0 : c->d_rec + static_cast<size_t>(t - 1) * n;
+            hipLaunchKernelGGL(cpm::k_export_hour, dim3(nblk(n, 256)), dim3(256), 0, c->stream, zsrc,
+                               c->d_rec + static_cast<size_t>(t) * n, n, c->car_begin, d_state, d_f, d_f + n, d_f + 2 * n,
+                               d_f + 3 * n, travel ? c->d_dm : nullptr, c->d_dist, static_cast<int>(c->Z),
+                               static_cast<int>(c->T), t, static_cast<uint32_t>(c->T - 1 + t), seed);
+            e = hipGetLastError();
+            if (e == hipSuccess && state_out)
+                e = hipMemcpyAsync(state_out + static_cast<size_t>(t) * n, d_state, sizeof(int64_t) * n, hipMemcpyDeviceToHost, c->stream);
+            for (int k = 0; k < 4 && e == hipSuccess && trans_out; ++k)
+                e = hipMemcpyAsync(trans_out + (static_cast<size_t>(k) * c->T + t) * n, d_f + static_cast<size_t>(k) * n,
+                                   sizeof(double) * n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        dfree(d_cols);
+        if (e != hipSuccess) return fail(CPM_ERR_HIP, "compat export: %s", hipGetErrorString(e));
+    }
+    return CPM_OK;
+}
+
+int32_t cpm_last_kernel_ms(cpm_ctx *c, float *ms_out, int32_t cap, int32_t *n_out)
+{
+    CTX_TRY(c);
+    if (!ms_out || !n_out) return fail(CPM_ERR_ARG, "null output");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int n = std::min<int>(c->n_prof, cap);
+    for (int k = 0; k < n; ++k) HIP_TRY(hipEventElapsedTime(&ms_out[k], c->ev[2 * k], c->ev[2 * k + 1]));
+    *n_out = n;
+    return CPM_OK;
+}
+
+int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
+{
+    if (!c || !bytes_out) return fail(CPM_ERR_ARG, "null argument");
+    // B/T = Z*Z*8 (CDF slab) + Z*8 (p_drive) + C_g*8 (4 B zone in + 4 B out) + 2*Z*8 (counts)
+    *bytes_out = c->Z * c->Z * 8 + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
+    return CPM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// cpm_kernels.h -- HIP kernels of the sampler path for gfx950 (MI355X).
+//
+// Device data layout (all in HBM, owned by cpm_ctx):
+//   pdrive [T][Z]        f64   == Julia's column-major Z x T, zone contiguous
+//   cdf    [T][Z][Zp]    f64   canonical CDF rows, destination contiguous, row padded to
+//                              Zp = roundup(Z,16) with +inf (a row is a whole number of
+//                              128-B lines and starts on one)
+//   zone0  [C]           u32   current (initial) zone of each local car, 0-based
+//   rec    [T][C]        u32   per resampling hour: destination zone | drive flag << 31
+//   counts [2][T][Z]     i64   parking | driving zone x hour histogram (+1 word: q16 time sum)
+// Zone ids are 0-based on the device and 1-based on the host side of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cpm_rng.h"
+
+namespace cpm {
+
+constexpr uint32_t kDriveBit = 0x80000000u;
+constexpr uint32_t kZoneMask = 0x7fffffffu;
+constexpr double kTrueMin = 4.9406564584124654e-324;
+
+// ---------------------------------------------------------------------------------------
+// initializestates (src/initializestates.jl:11-16): global car g starts in zone g / cpz.
+// ---------------------------------------------------------------------------------------
+__global__ void k_init_states(uint32_t *zone0, int64_t car_begin, int64_t n, int64_t cpz)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) zone0[i] = static_cast<uint32_t>((car_begin + i) / cpz);
+}
+
+__global__ void k_zones_from_i64(uint32_t *zone0, const int64_t *zones1, int64_t n, int64_t Z, int *err)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int64_t z = zones1[i];
+        if (z < 1 || z > Z) { atomicOr(err, 1); z = 1; }
+        zone0[i] = static_cast<uint32_t>(z - 1);
+    }
+}
+
+__global__ void k_zones_to_i64(int64_t *zones1, const uint32_t *zone0, int64_t n)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) zones1[i] = static_cast<int64_t>(zone0[i] & kZoneMask) + 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Canonical CDF build.  Input: p_dest in the reference's layout p[o + Z*(d + Z*t)]
+// (origin fastest).  One lane per origin walks d left to right with a plain f64 running
+// sum -- exactly range_up = range_up + distribution[j] of src/resampling.jl:39; a tree scan
+// would move boundaries by ULPs and break bit-exactness.  Loads are coalesced across the
+// 64 origins of a wave; the 64x64 tile goes through LDS so the row-major stores are
+// coalesced too.  Also validates the table (NaN / negative entries -> *err).
+// ---------------------------------------------------------------------------------------
+constexpr int kCdfTile = 64;
+
+__global__ __launch_bounds__(kCdfTile) void k_build_cdf(const double *__restrict__ p, double *__restrict__ cdf,
+                                                        int Z, int Zp, int *err)
+{
+    __shared__ double tile[kCdfTile][kCdfTile + 1];
+    const int t = blockIdx.y;
+    const int o0 = blockIdx.x * kCdfTile;
+    const int lane = threadIdx.x;
+    const int o = o0 + lane;
+    const double *src = p + static_cast<size_t>(t) * Z * Z + o;
+    double *dst = cdf + (static_cast<size_t>(t) * Z + o0) * Zp;
+    double run = 0.0;
+    bool bad = false;
+    for (int d0 = 0; d0 < Zp; d0 += kCdfTile) {
+        if (o < Z) {
+#pragma unroll 8
+            for (int j = 0; j < kCdfTile; ++j) {
+                int d = d0 + j;
+                double v;
+                if (d < Z) {
+                    double x = src[static_cast<size_t>(d) * Z];
+                    bad |= !(x >= 0.0);
+                    run = run + x;
+                    v = run;
+                } else {
+                    v = __builtin_huge_val();
+                }
+                tile[lane][j] = v;
+            }
+        }
+        __syncthreads();
+        int nrow = min(kCdfTile, Z - o0);
+        int d = d0 + lane;
+        if (d < Zp)
+            for (int r = 0; r < nrow; ++r) dst[static_cast<size_t>(r) * Zp + d] = tile[r][lane];
+        __syncthreads();
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Synthetic tables of SURVEY.md 8(d) (bench / parity inputs), bit-identical to
+// orc_synth_p_drive / orc_synth_p_dest_dense of the oracle.
+// ---------------------------------------------------------------------------------------
+__global__ void k_synth_p_drive(double *pdrive, int Z, int T, uint64_t table_seed)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Z * T) return;
+    int z = i % Z, t = i / Z;
+    double u = table_uniform(table_seed, z, t, 0, kStreamPDrive);
+    pdrive[i] = 0.1 + 0.8 * u;
+}
+
+// one thread per (origin, hour): sequential row sum, then the normalised row, written in
+// the reference's layout (origin fastest -> coalesced across the wave)
+__global__ void k_synth_p_dest(double *__restrict__ p, int Z, uint64_t table_seed)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    if (o >= Z) return;
+    double nf = 0.0;
+    for (int d = 0; d < Z; ++d) {
+        double u = table_uniform(table_seed, o, d, t, kStreamPDest);
+        double w = (o == d) ? 0.0 : u * u;
+        nf = nf + w;
+    }
+    double *dst = p + static_cast<size_t>(t) * Z * Z + o;
+    for (int d = 0; d < Z; ++d) {
+        double u = table_uniform(table_seed, o, d, t, kStreamPDest);
+        double w = (o == d) ? 0.0 : u * u;
+        if (nf > 0) w = w / nf;
+        dst[static_cast<size_t>(d) * Z] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Categorical draw on a canonical CDF row: first j with u <= cdf[j]  ==  the chained test
+// range_low < u <= range_up of src/resampling.jl:38-45 for u > 0.  Deviation D1 (the
+// reference leaves destination = 0 and crashes, Appendix A-7) is folded into the bounds:
+// u == 0 -> first zone with p > 0 ; u > cdf[Z-1] -> last zone with p > 0.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double clamp_u(double u, double last)
+{
+    double ue = (u == 0.0) ? kTrueMin : u;
+    return (ue > last) ? last : ue;
+}
+
+template <typename RowT>
+__device__ __forceinline__ int lower_bound_row(RowT row, int n, double ue)
+{
+    int lo = 0;
+    while (n > 0) {
+        int half = n >> 1;
+        double v = row[lo + half];
+        if (v < ue) {
+            lo += half + 1;
+            n -= half + 1;
+        } else {
+            n = half;
+        }
+    }
+    return lo;
+}
+
+// travel time of one driving car-hour (src/resampling.jl:57-69), q16 fixed point
+__device__ __forceinline__ long long travel_time_q16(const double *__restrict__ dm, int Z, int T, int t,
+                                                     uint32_t origin, uint32_t dest, uint64_t seed,
+                                                     uint64_t car, uint32_t step)
+{
+    if (origin == dest) return q16(300.0);
+    size_t cell = origin + static_cast<size_t>(Z) * (dest + static_cast<size_t>(Z) * t);
+    double mean = dm[cell];
+    double sd = dm[cell + static_cast<size_t>(Z) * Z * T];
+    if (sd == 0) sd = 0.1 * mean;
+    return q16(truncnormal_pm10(seed, car, step, 1, mean, sd));
+}
+
+// ---------------------------------------------------------------------------------------
+// CPM_KERNEL_CAR: one hour, one thread per car.  Bernoulli (src/resampling.jl:11-22) and
+// categorical (:26-49) draw, state update (:81-83) folded into the record written for the
+// next hour.  The CDF row is searched where it lies (HBM / MALL / L2).
+// ---------------------------------------------------------------------------------------
+template <bool TRAVEL>
+__global__ __launch_bounds__(256) void k_step_car(const uint32_t *__restrict__ zin, uint32_t *__restrict__ rec_out,
+                                                  const double *__restrict__ pdrive_t,
+                                                  const double *__restrict__ cdf_t, int Z, int Zp, int64_t n,
+                                                  int64_t car_begin, uint32_t step, uint64_t seed,
+                                                  const double *__restrict__ dm, int T, int t,
+                                                  unsigned long long *tt_sum)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    long long tt = 0;
+    if (i < n) {
+        uint32_t zone = zin[i] & kZoneMask;
+        uint64_t car = static_cast<uint64_t>(car_begin + i);
+        double ub, uc;
+        car_uniforms(seed, car, step, 0, ub, uc);
+        bool drive = ub <= pdrive_t[zone];
+        uint32_t dest = zone;
+        if (drive) {
+            const double *row = cdf_t + static_cast<size_t>(zone) * Zp;
+            double last = row[Z - 1];
+            if (last != 0.0) dest = static_cast<uint32_t>(lower_bound_row(row, Z, clamp_u(uc, last)));
+            if (TRAVEL) tt = travel_time_q16(dm, Z, T, t, zone, dest, seed, car, step);
+        }
+        rec_out[i] = dest | (drive ? kDriveBit : 0u);
+    }
+    if (TRAVEL) {
+        // wave-level sum, one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) tt += __shfl_down(tt, off, 64);
+        if ((threadIdx.x & 63) == 0 && tt != 0) atomicAdd(tt_sum, static_cast<unsigned long long>(tt));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Zone x hour histogram of saveresults (src/saveresults.jl:8-17): parking[z,t] counts every
+// car whose state at hour t is z (drivers included), driving[z,t] those that drive, binned by
+// origin.  One (chunk, hour) per workgroup; bins are privatised in LDS (2 x Z u32) and
+// flushed with contiguous global atomics, so HBM sees 8 B per car-hour and Z*8 B per block.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_histogram(const uint32_t *__restrict__ zone0,
+                                                    const uint32_t *__restrict__ rec, int64_t n, int Z,
+                                                    unsigned long long *__restrict__ parking,
+                                                    unsigned long long *__restrict__ driving, int64_t chunk)
+{
+    extern __shared__ uint32_t bins[];
+    uint32_t *lp = bins, *ld = bins + Z;
+    const int t = blockIdx.y;
+    for (int z = threadIdx.x; z < 2 * Z; z += blockDim.x) bins[z] = 0;
+    __syncthreads();
+    const uint32_t *zsrc = (t == 0) ? zone0 : rec + static_cast<size_t>(t - 1) * n;
+    const uint32_t *fsrc = rec + static_cast<size_t>(t) * n;
+    int64_t i0 = static_cast<int64_t>(blockIdx.x) * chunk;
+    int64_t i1 = min(i0 + chunk, n);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t z = zsrc[i] & kZoneMask;
+        uint32_t f = fsrc[i] >> 31;
+        atomicAdd(&lp[z], 1u);
+        if (f) atomicAdd(&ld[z], 1u);
+    }
+    __syncthreads();
+    for (int z = threadIdx.x; z < Z; z += blockDim.x) {
+        uint32_t a = lp[z], b = ld[z];
+        if (a) atomicAdd(&parking[static_cast<size_t>(t) * Z + z], static_cast<unsigned long long>(a));
+        if (b) atomicAdd(&driving[static_cast<size_t>(t) * Z + z], static_cast<unsigned long long>(b));
+    }
+}
+
+// fallback for Z too large for LDS bins
+__global__ void k_histogram_global(const uint32_t *__restrict__ zone0, const uint32_t *__restrict__ rec,
+                                   int64_t n, int Z, unsigned long long *parking, unsigned long long *driving)
+{
+    const int t = blockIdx.y;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t z = ((t == 0) ? zone0[i] : rec[static_cast<size_t>(t - 1) * n + i]) & kZoneMask;
+    uint32_t f = rec[static_cast<size_t>(t) * n + i] >> 31;
+    atomicAdd(&parking[static_cast<size_t>(t) * Z + z], 1ull);
+    if (f) atomicAdd(&driving[static_cast<size_t>(t) * Z + z], 1ull);
+}
+
+// ---------------------------------------------------------------------------------------
+// Compat export: one hour column of the reference's state_matrix / transition_matrix
+// (src/initializestates.jl:6-7): state[:,t], trans[:,t,1..4].  Travel time / distance are
+// re-derived from the same Philox streams, so nothing extra is stored per car.
+// ---------------------------------------------------------------------------------------
+__global__ void k_export_hour(const uint32_t *__restrict__ zsrc, const uint32_t *__restrict__ rec_t, int64_t n,
+                              int64_t car_begin, int64_t *__restrict__ state_col, double *__restrict__ drive_col,
+                              double *__restrict__ dest_col, double *__restrict__ time_col,
+                              double *__restrict__ dist_col, const double *__restrict__ dm,
+                              const double *__restrict__ dist, int Z, int T, int t, uint32_t step, uint64_t seed)
+{
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t zone = zsrc[i] & kZoneMask;
+    uint32_t r = rec_t[i];
+    uint32_t dest = r & kZoneMask;
+    bool drive = (r & kDriveBit) != 0;
+    state_col[i] = static_cast<int64_t>(zone) + 1;
+    drive_col[i] = drive ? 1.0 : 0.0;
+    dest_col[i] = static_cast<double>(dest) + 1.0;
+    double tm = 0.0, ds = 0.0;
+    if (drive && dm != nullptr) {
+        if (zone == dest) {
+            tm = 300.0;
+            ds = 1.0;
+        } else {
+            uint64_t car = static_cast<uint64_t>(car_begin + i);
+            size_t cell = zone + static_cast<size_t>(Z) * (dest + static_cast<size_t>(Z) * t);
+            double mean = dm[cell];
+            double sd = dm[cell + static_cast<size_t>(Z) * Z * T];
+            if (sd == 0) sd = 0.1 * mean;
+            tm = truncnormal_pm10(seed, car, step, 1, mean, sd);
+            mean = dist[zone + static_cast<size_t>(Z) * dest];
+            ds = truncnormal_pm10(seed, car, step, 2, mean, 0.1 * mean);
+        }
+    }
+    time_col[i] = tm;
+    dist_col[i] = ds;
+}
+
+}  // namespace cpm

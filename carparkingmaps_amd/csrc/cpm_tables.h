@@ -1,0 +1,122 @@
+// cpm_tables.h -- device builders of the probability tables (src/createpdrive.jl,
+// src/createpdestin.jl).  Input: datamatrix[o + Z*(d + Z*(t + T*k))] and dist[o + Z*d] in the
+// reference's column-major layout; every kernel puts the origin on the lane so that all
+// HBM accesses are coalesced (the reference walks the same arrays at stride Z or Z*Z).
+// Sums run left to right over the destination in f64, like the reference's loops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cpm {
+
+// Julia's maximum/minimum propagate NaN (Appendix A-3); fmax/fmin would not.
+__device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
+__device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
+
+// mean_sum[i,t] = mean over non-zero j of datamatrix[i,j,t,1] / dist[i,j]   (createpdrive.jl:10-21)
+__global__ void k_pdrive_mean(const double *__restrict__ dm, const double *__restrict__ dist,
+                              double *__restrict__ mean_sum, int Z)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    if (i >= Z) return;
+    const double *src = dm + static_cast<size_t>(t) * Z * Z + i;
+    double s = 0.0;
+    long long counter = 0;
+    for (int j = 0; j < Z; ++j) {
+        double m = src[static_cast<size_t>(j) * Z];
+        if (m != 0) {
+            s = s + m / dist[i + static_cast<size_t>(j) * Z];
+            counter += 1;
+        }
+    }
+    mean_sum[i + static_cast<size_t>(t) * Z] = s / static_cast<double>(counter);  // 0/0 = NaN
+}
+
+// exponent modes: Float64^Float64 of the reference; 0.5, 1, 2 are evaluated exactly
+__device__ __forceinline__ double pow_f64(double x, double e)
+{
+    if (e == 0.5) return sqrt(x);
+    if (e == 1.0) return x;
+    if (e == 2.0) return x * x;
+    return pow(x, e);
+}
+
+__device__ __forceinline__ double pow_int(double x, long n)
+{
+    if (n == 0) return 1.0;
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return x * x * x;
+    long t = 0, m = n;  // Base.power_by_squaring order
+    while ((m & 1) == 0) { m >>= 1; ++t; }
+    double xx = x;
+    for (long i = 0; i < t; ++i) xx *= xx;
+    double yy = xx;
+    m >>= 1;
+    while (m > 0) {
+        xx *= xx;
+        if (m & 1) yy *= xx;
+        m >>= 1;
+    }
+    return yy;
+}
+
+// p_drive[i,t] = p_min + (p_max - p_min) * ((ms - min) / (max - min))^e_drive   (createpdrive.jl:22-33)
+__global__ void k_pdrive_final(const double *__restrict__ mean_sum, double *__restrict__ pdrive, int Z, int T,
+                               double p_min, double p_max, double e_drive)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Z) return;
+    double mx = mean_sum[i], mn = mean_sum[i];
+    for (int t = 1; t < T; ++t) {
+        double v = mean_sum[i + static_cast<size_t>(t) * Z];
+        mx = jl_max(mx, v);
+        mn = jl_min(mn, v);
+    }
+    for (int t = 0; t < T; ++t) {
+        double v = 0.0;
+        if (mx > 0) v = p_min + (p_max - p_min) * pow_f64((mean_sum[i + static_cast<size_t>(t) * Z] - mn) / (mx - mn), e_drive);
+        pdrive[i + static_cast<size_t>(t) * Z] = v;
+    }
+}
+
+// unnormalised p_dest[i,j,t] = ((m - min_t m) / (max_t m - min_t m))^e_dest   (createpdestin.jl:10-28)
+__global__ void k_pdest_weights(const double *__restrict__ dm, double *__restrict__ p, int Z, int T, double e_dest,
+                                int e_is_integer)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= Z) return;
+    size_t base = i + static_cast<size_t>(j) * Z;
+    size_t slab = static_cast<size_t>(Z) * Z;
+    double mx = dm[base], mn = dm[base];
+    for (int t = 1; t < T; ++t) {
+        double v = dm[base + t * slab];
+        mx = jl_max(mx, v);
+        mn = jl_min(mn, v);
+    }
+    for (int t = 0; t < T; ++t) {
+        double w = 0.0;
+        if (mx > 0) {
+            double x = (dm[base + t * slab] - mn) / (mx - mn);
+            w = e_is_integer ? pow_int(x, static_cast<long>(e_dest)) : pow_f64(x, e_dest);
+        }
+        p[base + t * slab] = w;
+    }
+}
+
+// normalise per (i,t): nf = sum_j p[i,j,t] left to right; divide if nf > 0   (createpdestin.jl:31-46)
+__global__ void k_pdest_normalise(double *__restrict__ p, int Z)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int t = blockIdx.y;
+    if (i >= Z) return;
+    double *row = p + static_cast<size_t>(t) * Z * Z + i;
+    double nf = 0.0;
+    for (int j = 0; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
+    if (nf > 0)
+        for (int j = 0; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
+}
+
+}  // namespace cpm

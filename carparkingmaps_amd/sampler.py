@@ -1,0 +1,172 @@
+"""Sampler: thin object wrapper over the C ABI (include/cpm.h) with numpy arrays in the
+reference's layout (Fortran order, 1-based zone ids).  One Sampler = one cpm_ctx = one GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f64(a, shape=None):
+    a = np.asfortranarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Sampler:
+    """Device-resident tables + car state for `number_zones` zones and T hours on one GPU."""
+
+    def __init__(self, number_zones, T=24, device=0):
+        self._L = _lib.load()
+        self.Z, self.T, self.device = int(number_zones), int(T), int(device)
+        h = C.c_void_p()
+        _lib.check(self._L.cpm_create(C.byref(h), self.Z, self.T, self.device))
+        self._h = h
+        self.C_total = self.cars_per_zone = self.car_begin = self.car_count = 0
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cpm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- options -----------------------------------------------------------
+    def set_kernel(self, kernel):
+        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
+
+    def set_profile(self, on=True):
+        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(bool(on))))
+
+    def set_stream(self, hip_stream):
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        _lib.check(self._L.cpm_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        _lib.check(self._L.cpm_sync(self._h))
+
+    # -- tables ------------------------------------------------------------
+    def set_p_drive(self, p_drive):
+        a = _f64(p_drive, (self.Z, self.T))
+        _lib.check(self._L.cpm_set_p_drive(self._h, _vp(a)))
+
+    def set_p_dest(self, p_dest):
+        a = _f64(p_dest, (self.Z, self.Z, self.T))
+        _lib.check(self._L.cpm_set_p_dest(self._h, _vp(a)))
+
+    def set_datamatrix(self, datamatrix, distance_matrix_km):
+        a = _f64(datamatrix, (self.Z, self.Z, self.T, 2))
+        d = _f64(distance_matrix_km, (self.Z, self.Z))
+        _lib.check(self._L.cpm_set_datamatrix(self._h, _vp(a), _vp(d)))
+
+    def build_p_drive(self, p_min, p_max, e_drive, want=True):
+        out = np.zeros((self.Z, self.T), dtype=np.float64, order="F") if want else None
+        _lib.check(self._L.cpm_build_p_drive(self._h, float(p_min), float(p_max), float(e_drive), _vp(out)))
+        return out
+
+    def build_p_dest(self, e_dest, want=True):
+        out = np.zeros((self.Z, self.Z, self.T), dtype=np.float64, order="F") if want else None
+        is_int = int(isinstance(e_dest, (int, np.integer)) and not isinstance(e_dest, bool))
+        _lib.check(self._L.cpm_build_p_dest(self._h, float(e_dest), is_int, _vp(out)))
+        return out
+
+    def synth_tables(self, table_seed):
+        _lib.check(self._L.cpm_synth_tables(self._h, int(table_seed)))
+
+    def get_p_drive(self):
+        out = np.zeros((self.Z, self.T), dtype=np.float64, order="F")
+        _lib.check(self._L.cpm_get_p_drive(self._h, _vp(out)))
+        return out
+
+    def get_cdf_row(self, origin, hour):
+        out = np.zeros(self.Z, dtype=np.float64)
+        _lib.check(self._L.cpm_get_cdf_row(self._h, int(origin), int(hour), _vp(out)))
+        return out
+
+    # -- cars --------------------------------------------------------------
+    def init_states(self, C_total, cars_per_zone, car_begin=0, car_count=None):
+        car_count = int(C_total) - int(car_begin) if car_count is None else int(car_count)
+        _lib.check(self._L.cpm_init_states(self._h, int(C_total), int(cars_per_zone), int(car_begin), car_count))
+        self.C_total, self.cars_per_zone = int(C_total), int(cars_per_zone)
+        self.car_begin, self.car_count = int(car_begin), car_count
+
+    def set_state(self, zones):
+        z = np.ascontiguousarray(zones, dtype=np.int64)
+        if z.shape != (self.car_count,):
+            raise ValueError(f"expected {self.car_count} zones, got {z.shape}")
+        _lib.check(self._L.cpm_set_state(self._h, _vp(z)))
+
+    def get_state(self):
+        out = np.zeros(self.car_count, dtype=np.int64)
+        _lib.check(self._L.cpm_get_state(self._h, _vp(out)))
+        return out
+
+    def solve_ivp(self, seed, want=True):
+        out = np.zeros(self.car_count, dtype=np.int64) if want else None
+        _lib.check(self._L.cpm_solve_ivp(self._h, int(seed), _vp(out)))
+        return out
+
+    def solve_ivp_async(self, seed):
+        _lib.check(self._L.cpm_solve_ivp_async(self._h, int(seed)))
+
+    def resample(self, seed, travel=False, want_state=False, want_trans=False):
+        """Returns dict(parking, driving: (Z,T) int64 F-order; sum_tt_q16: int; state, trans or None)."""
+        parking = np.zeros((self.Z, self.T), dtype=np.int64, order="F")
+        driving = np.zeros((self.Z, self.T), dtype=np.int64, order="F")
+        state = np.zeros((self.car_count, self.T), dtype=np.int64, order="F") if want_state else None
+        trans = np.zeros((self.car_count, self.T, 4), dtype=np.float64, order="F") if want_trans else None
+        tt = C.c_int64(0)
+        flags = _lib.CPM_FLAG_TRAVEL if travel else 0
+        _lib.check(self._L.cpm_resample(self._h, int(seed), flags, _vp(parking), _vp(driving),
+                                        C.cast(C.byref(tt), C.c_void_p), _vp(state), _vp(trans)))
+        return dict(parking=parking, driving=driving, sum_tt_q16=int(tt.value), state=state, trans=trans)
+
+    def resample_dev(self, seed, d_counts_ptr, travel=False):
+        """Enqueue on the context's stream; d_counts_ptr = device address of int64[2*T*Z+1]."""
+        flags = _lib.CPM_FLAG_TRAVEL if travel else 0
+        _lib.check(self._L.cpm_resample_dev(self._h, int(seed), flags, C.c_void_p(int(d_counts_ptr))))
+
+    def counts_words(self):
+        return 2 * self.T * self.Z + 1
+
+    def last_kernel_ms(self):
+        buf = (C.c_float * 8192)()
+        n = C.c_int32(0)
+        _lib.check(self._L.cpm_last_kernel_ms(self._h, C.cast(buf, C.c_void_p), 8192, C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
+    def algorithmic_bytes_per_hour(self):
+        b = C.c_int64(0)
+        _lib.check(self._L.cpm_algorithmic_bytes_per_hour(self._h, C.byref(b)))
+        return int(b.value)
+
+
+def device_count():
+    n = C.c_int32(0)
+    _lib.check(_lib.load().cpm_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cu = C.c_int32(0)
+    mem = C.c_int64(0)
+    _lib.check(_lib.load().cpm_device_info(device, name, 256, C.byref(cu), C.byref(mem)))
+    return dict(name=name.value.decode(), cu_count=cu.value, hbm_bytes=mem.value)

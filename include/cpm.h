@@ -1,0 +1,151 @@
+/*
+ * cpm.h -- C ABI of libcpm_hip.so: the MI355X (gfx950) implementation of the
+ * CarParkingMaps HMM traffic-flow sampler path.
+ *
+ * This is the drop-in boundary.  The reference (Julia, /root/reference) has no
+ * FFI of its own; these are the entry points a `ccall` shim binds so that
+ * main.jl:82-102 keeps its call surface (julia/CarParkingMapsAMD.jl and
+ * INTEGRATION.md show the binding).  Each entry cites the reference interface
+ * it replaces.
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 = ok, < 0 = error; the message of the
+ *    last error on the calling thread is cpm_last_error().  No exception and no
+ *    abort crosses the boundary.
+ *  - host arrays are the reference's Julia arrays as they lie in memory:
+ *    column-major Float64 / Int64, zone ids 1-based.  They are borrowed for the
+ *    duration of the call only (Julia side: GC.@preserve).
+ *      p_drive    Z x T          (src/createpdrive.jl:4,36)
+ *      p_dest     Z x Z x T      (src/createpdestin.jl:4,48)
+ *      datamatrix Z x Z x T x 2  (src/createdatamatrix.jl:7,25)
+ *      dist       Z x Z          (src/processgeodata.jl:150)
+ *      state      C x T  Int64   (src/initializestates.jl:6,17)
+ *      trans      C x T x 4      (src/initializestates.jl:7)
+ *      counts     Z x T  Int64   (src/saveresults.jl:8-9, held as Float64 there)
+ *  - the library owns all device memory inside the opaque cpm_ctx.  A context is
+ *    bound to ONE device and is not thread-safe; distinct contexts may be used
+ *    from distinct threads / processes (one process per GPU for multi-GPU runs;
+ *    the count tensors are summed by the host layer with one RCCL all-reduce).
+ *  - functions without the _dev/_async suffix block until the device is done.
+ *  - there is NO CPU fallback: if no HIP device is usable every call fails.
+ *
+ * RNG contract (the reference is unseeded: bare rand(), src/resampling.jl:13,29):
+ * Philox4x32-10, key = seed, counter = (car_lo, car_hi, step, stream) with car
+ * the GLOBAL 0-based car id, step 0..T-2 for the initial-value problem and
+ * T-1..2T-2 for resampling, stream 0 = (Bernoulli u, categorical u), streams
+ * >= 1 = travel time / distance attempts.  Results are therefore independent
+ * of thread, workgroup, GPU and shard layout.
+ */
+#ifndef CPM_H
+#define CPM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPM_OK 0
+#define CPM_ERR_ARG (-1)    /* bad argument */
+#define CPM_ERR_HIP (-2)    /* HIP runtime error / no device */
+#define CPM_ERR_STATE (-3)  /* call order: a required table or state is missing */
+#define CPM_ERR_TABLE (-4)  /* p_dest holds NaN / negative entries (the reference would
+                               crash with BoundsError one hour later, Appendix A-7) */
+#define CPM_ERR_NOMEM (-5)
+
+/* cpm_resample flags */
+#define CPM_FLAG_TRAVEL 1u      /* pass 3 of src/resampling.jl:53-78 (needs cpm_set_datamatrix) */
+
+/* search kernels (cpm_set_option CPM_OPT_KERNEL) */
+#define CPM_KERNEL_AUTO 0
+#define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
+#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS */
+
+#define CPM_OPT_KERNEL 1
+#define CPM_OPT_PROFILE 2       /* 1: bracket every hourly kernel with hipEvents */
+
+typedef struct cpm_ctx cpm_ctx;
+
+const char *cpm_last_error(void);
+int32_t cpm_version(void);
+int32_t cpm_device_count(int32_t *n_out);
+/* name[len] <- device name; *cu_count, *hbm_bytes optional */
+int32_t cpm_device_info(int32_t device_id, char *name, int32_t len, int32_t *cu_count,
+                        int64_t *hbm_bytes);
+
+/* Z = number_zones (main.jl:59), T = 24 (main.jl:42) */
+int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id);
+int32_t cpm_destroy(cpm_ctx *ctx);
+int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own */
+int32_t cpm_set_stream(cpm_ctx *ctx, void *hip_stream);
+int32_t cpm_sync(cpm_ctx *ctx);
+
+/* ---- probability tables ------------------------------------------------- */
+/* takes the array createpdrive returns (src/createpdrive.jl:36; main.jl:82) */
+int32_t cpm_set_p_drive(cpm_ctx *ctx, const double *p_drive);
+/* takes the array createpdestin returns (src/createpdestin.jl:48; main.jl:85); builds the
+ * canonical CDF on device: sequential left-to-right f64 sum per (origin, hour), the
+ * accumulation of src/resampling.jl:39 */
+int32_t cpm_set_p_dest(cpm_ctx *ctx, const double *p_dest);
+/* uploads createdatamatrix's array (main.jl:79) and processgeodata's distance matrix
+ * (main.jl:59); enables cpm_build_* and CPM_FLAG_TRAVEL */
+int32_t cpm_set_datamatrix(cpm_ctx *ctx, const double *datamatrix, const double *dist);
+/* createpdrive(datamatrix, distance_matrix_km, number_zones) with the script globals
+ * p_min, p_max, e_drive passed explicitly (src/createpdrive.jl:3-38); installs the table and
+ * optionally returns it */
+int32_t cpm_build_p_drive(cpm_ctx *ctx, double p_min, double p_max, double e_drive,
+                          double *p_drive_out_or_null);
+/* createpdestin(datamatrix, number_zones) with e_dest explicit (src/createpdestin.jl:3-50);
+ * e_is_integer != 0 reproduces Julia's Float64^Int (main.jl:38: e_dest = 2) */
+int32_t cpm_build_p_dest(cpm_ctx *ctx, double e_dest, int32_t e_is_integer,
+                         double *p_dest_out_or_null);
+/* read back the installed tables (Z x T / Z x Z x T, column-major) */
+int32_t cpm_get_p_drive(cpm_ctx *ctx, double *p_drive_out);
+int32_t cpm_get_cdf_row(cpm_ctx *ctx, int64_t origin1, int64_t hour1, double *cdf_row_out);
+
+/* ---- cars --------------------------------------------------------------- */
+/* initializestates(C) (src/initializestates.jl:4-22; main.jl:88): global car g (0-based) starts
+ * in zone g / cars_per_zone + 1.  This context simulates the shard
+ * [car_begin, car_begin + car_count) of the C_total cars. */
+int32_t cpm_init_states(cpm_ctx *ctx, int64_t C_total, int64_t cars_per_zone, int64_t car_begin,
+                        int64_t car_count);
+/* state_matrix[:,1] = initial_state (main.jl:92): zones 1-based, car_count entries */
+int32_t cpm_set_state(cpm_ctx *ctx, const int64_t *zones);
+int32_t cpm_get_state(cpm_ctx *ctx, int64_t *zones_out);
+/* solveinitialvalueproblem (src/solveinitialvalueproblem.jl:4-62; main.jl:91): T-1 steps,
+ * advances the context's current state in place and optionally returns it */
+int32_t cpm_solve_ivp(cpm_ctx *ctx, uint64_t seed, int64_t *initial_state_out_or_null);
+/* resampling + the histogram of saveresults + the sum of averagedrivingtime, fused
+ * (src/resampling.jl:3-89; src/saveresults.jl:6-17; src/averagedrivingtime.jl:7-8;
+ * main.jl:95,98,102).  Starts from the context's current state and leaves it unchanged, so
+ * it can be called repeatedly (the model-selection loops, README.md:1180).
+ *   parking_counts, driving_counts : Z x T Int64 (this shard's cars only)
+ *   sum_travel_time_q16            : sum of transition_matrix[:,:,3] in 2^-16 s units (0 without
+ *                                    CPM_FLAG_TRAVEL); order-free, so shards add exactly
+ *   state_out_or_null              : C x T Int64, the reference's state_matrix
+ *   trans_out_or_null              : C x T x 4 Float64, the reference's transition_matrix */
+int32_t cpm_resample(cpm_ctx *ctx, uint64_t seed, uint32_t flags, int64_t *parking_counts,
+                     int64_t *driving_counts, int64_t *sum_travel_time_q16,
+                     int64_t *state_out_or_null, double *trans_out_or_null);
+
+/* ---- device-resident forms for the host layer (torch tensors, RCCL) ----- */
+/* enqueue the fused resample on the context's stream and return without synchronising.
+ * d_counts: DEVICE pointer to int64[2*T*Z + 1] = parking[T][Z] | driving[T][Z] | sum_tt_q16,
+ * zeroed and filled by the call (ready for one all-reduce). */
+int32_t cpm_resample_dev(cpm_ctx *ctx, uint64_t seed, uint32_t flags, void *d_counts);
+int32_t cpm_solve_ivp_async(cpm_ctx *ctx, uint64_t seed);
+/* procedural synthetic tables of SURVEY.md 8(d), generated on device (bench inputs):
+ * p_drive = 0.1 + 0.8 u ; dense p_dest ~ u^2, zero diagonal, row-normalised */
+int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
+/* with CPM_OPT_PROFILE: durations (ms) of the hourly sampler kernels launched by
+ * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
+ * stream); returns the number written through *n_out */
+int32_t cpm_last_kernel_ms(cpm_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
+/* algorithmic HBM bytes of one hourly sampler launch */
+int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *ctx, int64_t *bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

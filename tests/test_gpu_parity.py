@@ -1,0 +1,283 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact for every
+integer result.  Run on the GPU box: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import SIM_SEED, TABLE_SEED
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [pytest.param(1, id="car"), pytest.param(2, id="zone_lds")]  # CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS
+
+
+def _tables(O, Z, T=24, seed=TABLE_SEED):
+    return O.synth_p_drive(Z, T, seed), O.synth_p_dest_dense(Z, T, seed)
+
+
+def _zone0(C, cpz):
+    return np.arange(C, dtype=np.int64) // cpz + 1
+
+
+def test_device_is_gfx950(cpm):
+    info = cpm.device_info(0)
+    assert "gfx950" in info["name"], info
+
+
+def test_cdf_is_the_sequential_sum(cpm, O):
+    Z, T = 100, 24  # not a multiple of 16: exercises the row padding
+    _, p_dest = _tables(O, Z, T)
+    cdf = O.build_cdf(p_dest)
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_dest(p_dest)
+        for (o, t) in [(1, 1), (Z, T), (37, 5), (64, 24), (65, 1)]:
+            assert np.array_equal(s.get_cdf_row(o, t), cdf[t - 1, o - 1]), (o, t)
+
+
+def test_device_synth_tables_equal_oracle_synth(cpm, O):
+    Z, T = 130, 24
+    p_drive, p_dest = _tables(O, Z, T)
+    cdf = O.build_cdf(p_dest)
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED)
+        assert np.array_equal(s.get_p_drive(), p_drive)
+        for (o, t) in [(1, 1), (Z, T), (77, 13), (128, 2), (129, 24)]:
+            assert np.array_equal(s.get_cdf_row(o, t), cdf[t - 1, o - 1]), (o, t)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("Z,cpz", [(5, 3), (37, 11), (64, 64), (256, 100), (513, 7)])
+def test_ivp_and_counts_bit_exact(cpm, O, kernel, Z, cpz):
+    T, C = 24, Z * cpz
+    p_drive, p_dest = _tables(O, Z, T)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), want_state=True)
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(kernel)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.get_state(), _zone0(C, cpz))
+        init = s.solve_ivp(SIM_SEED)
+        assert np.array_equal(init, ref["zone0"])
+        r = s.resample(SIM_SEED)
+        assert np.array_equal(r["parking"], ref["parking"])
+        assert np.array_equal(r["driving"], ref["driving"])
+        assert (r["parking"].sum(axis=0) == C).all()
+        # the resample leaves the initial state untouched: a second call gives the same counts
+        r2 = s.resample(SIM_SEED)
+        assert np.array_equal(r2["parking"], ref["parking"]) and np.array_equal(r2["driving"], ref["driving"])
+        # densities: same count / C in f64 on both sides -> well inside the 1e-6 relative bound
+        dens = r["parking"] / C
+        np.testing.assert_allclose(dens, ref["parking"] / C, rtol=1e-6, atol=0)
+
+
+def test_compat_matrices_equal_the_faithful_oracle(cpm, O):
+    """state_matrix / transition_matrix (all four columns, travel time and distance included)
+    against the three-pass restatement of src/resampling.jl."""
+    Z, T, cpz = 24, 24, 9
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.5)
+    p_drive = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5)
+    p_dest = O.createpdestin(dm, Z, T, 2)
+    st, tr = O.initializestates(C, cpz, T)
+    init = O.solveinitialvalueproblem(st, tr, p_drive, p_dest, C, Z, SIM_SEED)
+    st, tr = O.initializestates(C, cpz, T)
+    st[:, 0] = init
+    O.resampling(st, tr, C, Z, p_drive, p_dest, dm, dist, SIM_SEED)
+    pk, dr, _ = O.histogram(Z, st, tr)
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.set_datamatrix(dm, dist)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), init)
+        r = s.resample(SIM_SEED, travel=True, want_state=True, want_trans=True)
+    assert np.array_equal(r["state"], st)
+    assert np.array_equal(r["trans"][:, :, 0], tr[:, :, 0])
+    assert np.array_equal(r["trans"][:, :, 1], tr[:, :, 1])
+    assert np.array_equal(r["trans"][:, :, 2], tr[:, :, 2])  # bit-exact: same +,-,*,/ sequence
+    assert np.array_equal(r["trans"][:, :, 3], tr[:, :, 3])
+    assert np.array_equal(r["parking"], pk.astype(np.int64))
+    assert np.array_equal(r["driving"], dr.astype(np.int64))
+    assert r["sum_tt_q16"] == O.sum_travel_time_q16(tr)
+    a_ref = O.averagedrivingtime(C, 0.0, tr)
+    a_gpu = (r["sum_tt_q16"] / 65536.0) / (C * T * 3600.0)
+    assert abs(a_gpu - a_ref) <= 1e-6 * abs(a_ref)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_travel_time_sum_bit_exact(cpm, O, kernel):
+    Z, T, cpz = 40, 24, 50
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.3)
+    p_drive = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5)
+    p_dest = O.createpdestin(dm, Z, T, 2)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(kernel)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.set_datamatrix(dm, dist)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        r = s.resample(SIM_SEED, travel=True)
+    assert np.array_equal(r["parking"], ref["parking"])
+    assert np.array_equal(r["driving"], ref["driving"])
+    assert r["sum_tt_q16"] == ref["sum_tt_q16"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_edge_rows(cpm, O, kernel):
+    """Zero rows (dest = origin, still counted as driving: Appendix A-8), p_drive 0 / 1 / NaN zones
+    (A-3, A-6), rows that sum to less than one (fall-through, deviation D1), sparse rows with
+    leading / trailing zero-probability zones (A-9)."""
+    Z, T, cpz = 48, 24, 40
+    C = Z * cpz
+    p_drive, p_dest = _tables(O, Z, T)
+    p_drive[0, :] = 0.0
+    p_drive[1, :] = 1.0
+    p_drive[2, :] = np.nan
+    p_dest[3, :, :] = 0.0                    # zero row, every hour
+    p_dest[4, :, :] *= 0.5                   # sums to 0.5: half the draws fall through -> last zone with p > 0
+    p_dest[4, Z - 3:, :] = 0.0
+    p_dest[5, :, :] = 0.0
+    p_dest[5, 7, :] = 1.0                    # point mass
+    p_dest[6, :10, :] = 0.0                  # leading zeros
+    p_dest[6, :, :] /= p_dest[6, :, :].sum(axis=0, keepdims=True)
+    p_dest = np.asfortranarray(p_dest)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    # the faithful three-pass form agrees with the fast twin on the same edge cases
+    st, tr = O.initializestates(C, cpz, T)
+    init = O.solveinitialvalueproblem(st, tr, p_drive, p_dest, C, Z, SIM_SEED)
+    assert np.array_equal(init, ref["zone0"])
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(kernel)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+    assert np.array_equal(r["parking"], ref["parking"])
+    assert np.array_equal(r["driving"], ref["driving"])
+    assert r["driving"][2].sum() == 0       # NaN zone never drives
+
+
+def test_nan_table_is_rejected(cpm, O):
+    Z, T = 20, 24
+    _, p_dest = _tables(O, Z, T)
+    p_dest[3, 4, 5] = np.nan
+    with cpm.Sampler(Z, T) as s:
+        with pytest.raises(cpm.CpmError) as e:
+            s.set_p_dest(p_dest)
+        assert e.value.status == -4
+
+
+def test_call_order_errors(cpm, O):
+    Z, T = 8, 24
+    p_drive, p_dest = _tables(O, Z, T)
+    with cpm.Sampler(Z, T) as s:
+        with pytest.raises(cpm.CpmError):
+            s.resample(1)                                                   # no tables
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        with pytest.raises(cpm.CpmError):
+            s.resample(1)                                                   # no cars
+        with pytest.raises(cpm.CpmError):
+            s.init_states(Z * 4 + 4, 4)                                     # more cars than zones * cpz
+        s.init_states(Z * 4, 4)
+        with pytest.raises(cpm.CpmError):
+            s.resample(1, travel=True)                                      # no datamatrix
+        with pytest.raises(cpm.CpmError):
+            s.set_state(np.full(Z * 4, Z + 1, dtype=np.int64))              # zone out of range
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_shards_sum_to_the_single_run(cpm, O, kernel):
+    """Philox is keyed by the global car id: any partition of the cars gives the same total
+    (SURVEY 8e); includes an empty shard and ragged shard sizes."""
+    from carparkingmaps_amd.distributed import shard_range
+    Z, T, cpz = 61, 24, 23
+    C = Z * cpz
+    p_drive, p_dest = _tables(O, Z, T)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    for world in (1, 3, 8):
+        pk = np.zeros((Z, T), dtype=np.int64)
+        dr = np.zeros((Z, T), dtype=np.int64)
+        with cpm.Sampler(Z, T) as s:
+            s.set_kernel(kernel)
+            s.set_p_drive(p_drive)
+            s.set_p_dest(p_dest)
+            for rank in range(world):
+                b, n = shard_range(C, rank, world)
+                s.init_states(C, cpz, b, n)
+                s.solve_ivp(SIM_SEED, want=False)
+                r = s.resample(SIM_SEED)
+                pk += r["parking"]
+                dr += r["driving"]
+            s.init_states(C, cpz, C, 0)  # empty shard
+            r = s.resample(SIM_SEED)
+            assert r["parking"].sum() == 0
+        assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"]), world
+
+
+def test_table_builders_against_the_oracle(cpm, O):
+    """createpdrive / createpdestin on device vs the restatement.  Bit-exact except where the
+    reference's `^` goes through libm pow (e_drive = 0.5: device sqrt vs glibc pow; <= 1 ulp)."""
+    Z, T = 70, 24
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.2)
+    dm[5, :, :, :] = 0.0          # zone with no outgoing data: NaN mean -> p_drive 0 all day (A-3)
+    dm[6, :, 3, :] = 0.0          # one empty hour -> NaN poisons the whole zone (A-3)
+    dm = np.asfortranarray(dm)
+    with cpm.Sampler(Z, T) as s:
+        s.set_datamatrix(dm, dist)
+        for e_drive in (0.5, 1.0, 2.0, 0.7):
+            got = s.build_p_drive(0.1, 0.9, e_drive)
+            want = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, e_drive)
+            np.testing.assert_allclose(got, want, rtol=4e-16 if e_drive != 0.7 else 1e-14, atol=0, equal_nan=True)
+            assert (got[5] == 0).all() and (got[6] == 0).all()
+        for e_dest in (2, 2.0, 1, 3, 4.0, 0.5):
+            got = s.build_p_dest(e_dest)
+            want = O.createpdestin(dm, Z, T, e_dest)
+            if isinstance(e_dest, int) or e_dest in (2.0,):
+                assert np.array_equal(got, want), e_dest
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+
+
+def test_reference_call_surface_main_jl(cpm, O, tmp_path):
+    """main.jl:79-102 through the mirrored call surface, against the oracle run the same way."""
+    Z, T, cpz = 30, 24, 20
+    C = Z * cpz
+    cpm.params.cars_per_zone, cpm.params.T, cpm.params.seed = cpz, T, SIM_SEED
+    cpm.params.e_drive, cpm.params.e_dest, cpm.params.p_min, cpm.params.p_max = 1.0, 2, 0.1, 0.9
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.4)
+    try:
+        p_drive = cpm.createpdrive(dm, dist, Z)
+        p_dest = cpm.createpdestin(dm, Z)
+        assert np.array_equal(p_drive, O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 1.0))
+        assert np.array_equal(p_dest, O.createpdestin(dm, Z, T, 2))
+        state_matrix, transition_matrix = cpm.initializestates(C)
+        st, tr = O.initializestates(C, cpz, T)
+        assert np.array_equal(state_matrix, st) and np.array_equal(transition_matrix, tr)
+        initial_state = cpm.solveinitialvalueproblem(state_matrix, transition_matrix, p_drive, p_dest, C, Z)
+        init = O.solveinitialvalueproblem(st, tr, p_drive, p_dest, C, Z, SIM_SEED)
+        assert np.array_equal(initial_state, init)
+        state_matrix[:, 0] = initial_state
+        st, tr = O.initializestates(C, cpz, T)
+        st[:, 0] = init
+        state_matrix, transition_matrix = cpm.resampling(state_matrix, transition_matrix, C, Z, p_drive, p_dest, dm, dist)
+        O.resampling(st, tr, C, Z, p_drive, p_dest, dm, dist, SIM_SEED)
+        assert np.array_equal(state_matrix, st) and np.array_equal(transition_matrix, tr)
+        a = cpm.averagedrivingtime(C, 0, transition_matrix)
+        assert abs(a - O.averagedrivingtime(C, 0.0, tr)) <= 1e-12 * a
+        dens, act = cpm.saveresults(Z, state_matrix, transition_matrix, str(tmp_path), "data.csv", C)
+        pk, dr, d_ref = O.histogram(Z, st, tr)
+        assert np.array_equal(dens, d_ref)
+        np.testing.assert_allclose(act, O.trafficactivity(dr), rtol=1e-15)
+        lines = (tmp_path / "results_parkingdensities_data.csv").read_text().splitlines()
+        assert lines[0].split(",")[0] == "t = 1h" and len(lines) == Z + 1
+        fast = cpm.run_dataset(dm, dist, Z, travel=True)
+        assert np.array_equal(fast["parking"], pk.astype(np.int64))
+        assert abs(fast["A_drive_increment"] - a) <= 1e-6 * a
+    finally:
+        cpm.release()
+        cpm.params.__init__()
