@@ -151,7 +151,7 @@ def main():
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
                        "kernel": {0: "auto", 1: "car", 2: "zone_lds"}[args.kernel],
-                       "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 1}]",
+                       "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
                        "device": cpm.device_info(local_rank)["name"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -14,6 +14,7 @@
 #include "cpm_kernels.h"
 #include "cpm_tables.h"
 #include "cpm_zone_kernels.h"
+#include "cpm_zone2_kernels.h"
 
 namespace {
 
@@ -74,10 +75,11 @@ struct cpm_ctx {
     int64_t rec_cap = 0;
     bool have_state = false;
     // results
-    int64_t *d_counts = nullptr;  // [2*T*Z + 1]
+    int64_t *d_counts = nullptr;  // [2*T*Z + 2]
     int *d_err = nullptr;
     // zone-bucket path
     cpm::ZoneWork zw;
+    cpm::Zone2Work zw2;
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
@@ -218,10 +220,16 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     if (!c->have_state) return fail(CPM_ERR_STATE, "resample: no car state (cpm_init_states / cpm_set_state)");
     bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
     if (travel && !c->have_dm) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
-    size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 1);
+    size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_FUSED) {
+        return cpm::zone2_resample(c->zw2, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
+                                   d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                                   g_last_error);
+    }
     if (pick_kernel(c) == CPM_KERNEL_ZONE_LDS) {
         return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
@@ -245,6 +253,8 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
 {
     if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "solve_ivp: p_drive / p_dest not set");
     if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
+    c->zw.buckets0_valid = false;
+    c->zw2.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     // src/solveinitialvalueproblem.jl:8 : t = 1:(T-1), state update unconditional (:53)
     for (int t = 0; t < c->T - 1; ++t) {
@@ -307,7 +317,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
     if (e != hipSuccess) {
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -332,6 +342,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_counts);
     dfree(c->d_err);
     c->zw.release();
+    c->zw2.release();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -343,12 +354,25 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     CTX_TRY(c);
     switch (option) {
     case CPM_OPT_KERNEL:
-        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_LDS) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_FUSED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE:
         c->profile = value != 0;
         c->n_prof = 0;  // (re)start the record; hourly launches append until read or reset
+        return CPM_OK;
+    case CPM_OPT_ZONE_BLOCK:
+        if (value != 128 && value != 256 && value != 512 && value != 1024) return fail(CPM_ERR_ARG, "zone block %lld", (long long)value);
+        c->zw.block = static_cast<int>(value);
+        c->zw2.block = static_cast<int>(value);
+        return CPM_OK;
+    case CPM_OPT_ZONE_CPT:
+        if (value < 1 || value > 8) return fail(CPM_ERR_ARG, "cars per thread %lld", (long long)value);
+        c->zw2.cpt = static_cast<int>(value);
+        return CPM_OK;
+    case CPM_OPT_ABLATE:
+        c->zw.ablate = static_cast<int>(value);
+        c->zw2.ablate = static_cast<int>(value);
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown option %d", option);
@@ -520,6 +544,8 @@ int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int6
     c->C_total = C_total;
     c->cpz = cars_per_zone;
     c->car_begin = car_begin;
+    c->zw.buckets0_valid = false;
+    c->zw2.buckets0_valid = false;
     if (car_count > 0) {
         hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, car_begin,
                            car_count, cars_per_zone);
@@ -533,6 +559,8 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
 {
     CTX_TRY(c);
     if (!c->have_state) return fail(CPM_ERR_STATE, "set_state: cpm_init_states first (defines the car range)");
+    c->zw.buckets0_valid = false;
+    c->zw2.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (!zones) return fail(CPM_ERR_ARG, "null zones");
     int64_t *d_z = nullptr;
@@ -599,9 +627,18 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
     int saved_kernel = c->kernel;
     if (compat) c->kernel = CPM_KERNEL_CAR;  // the per-hour records of every car are kept by this path
     int32_t rc = resample_enqueue(c, seed, flags, c->d_counts);
+    size_t zt = static_cast<size_t>(c->Z * c->T);
+    if (rc == CPM_OK) {  // rank overflow in the fused zone path (pathological skew): redo with the unfused one
+        int64_t status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (status != 0) {
+            c->kernel = CPM_KERNEL_ZONE_LDS;
+            rc = resample_enqueue(c, seed, flags, c->d_counts);
+        }
+    }
     c->kernel = saved_kernel;
     if (rc != CPM_OK) return rc;
-    size_t zt = static_cast<size_t>(c->Z * c->T);
     HIP_TRY(hipMemcpyAsync(parking, c->d_counts, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(driving, c->d_counts + zt, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
     int64_t tt = 0;

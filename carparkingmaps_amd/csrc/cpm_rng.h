@@ -30,8 +30,11 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(kPhiloxM0, c0), lo0 = kPhiloxM0 * c0;
-        uint32_t hi1 = __umulhi(kPhiloxM1, c2), lo1 = kPhiloxM1 * c2;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
+        uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
+        uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
+        uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+        uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -55,6 +58,25 @@ __device__ __forceinline__ void car_uniforms(uint64_t seed, uint64_t car, uint32
                          static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
     u0 = u53(r.x, r.y);
     u1 = u53(r.z, r.w);
+}
+
+// Integer form of the Bernoulli draw.  u = k * 2^-53 with k the 53 high bits, so
+// u <= p  <=>  k <= floor(p * 2^53): the comparison of src/resampling.jl:15 without converting
+// the draw to f64.  NaN -> never drives, p >= 1 -> always, p < 0 -> never (Appendix A-3, A-6).
+__device__ __forceinline__ long long bernoulli_threshold(double p)
+{
+    if (!(p >= 0.0)) return -1;           // NaN or negative: k <= -1 is never true
+    if (p >= 1.0) return 0x7fffffffffffffffLL;
+    return static_cast<long long>(floor(p * 0x1.0p53));  // exact: scaling by a power of two
+}
+
+// (53-bit integer of the Bernoulli draw, f64 categorical uniform) of (car, step, stream 0)
+__device__ __forceinline__ void car_draws(uint64_t seed, uint64_t car, uint32_t step, long long &kb, double &uc)
+{
+    U4 r = philox4x32_10(static_cast<uint32_t>(car), static_cast<uint32_t>(car >> 32), step, 0u,
+                         static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+    kb = static_cast<long long>(((static_cast<uint64_t>(r.y) << 32) | r.x) >> 11);
+    uc = u53(r.z, r.w);
 }
 
 __device__ __forceinline__ double table_uniform(uint64_t seed, uint32_t a, uint32_t b, uint32_t c,

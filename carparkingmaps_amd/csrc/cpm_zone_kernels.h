@@ -1,8 +1,26 @@
-// cpm_zone_kernels.h -- CPM_KERNEL_ZONE_LDS path (cars bucketed by zone, CDF row in LDS).
+// cpm_zone_kernels.h -- CPM_KERNEL_ZONE_LDS: cars bucketed by zone, CDF row staged in LDS.
+//
+// The reference walks p_dest[origin,:,t] once per driving car (src/resampling.jl:34-45).  Here
+// the cars of one origin zone sit together, so the row is streamed from HBM exactly once per
+// hour (coalesced, 16 B per lane), kept in LDS, and every car of the zone searches it there.
+// Per hour t:
+//   k_zone_sample   one workgroup per origin zone: stage cdf[t][zone][:] in LDS; for each car of the
+//                   bucket: Philox -> Bernoulli (:11-22) -> categorical by binary search in LDS
+//                   (:26-49); writes dest|drive per slot, parking[t][zone] = bucket size,
+//                   driving[t][zone] = drivers (src/saveresults.jl:10-15) -- no histogram atomics.
+//   k_zone_hist     counting sort, pass 1: LDS-privatised histogram of the destinations of a
+//                   contiguous chunk of slots; one contiguous global atomic per (block, zone)
+//                   reserves the block's range in the zone's next bucket (ticket).
+//   k_zone_scatter  counting sort, pass 2: every block scans the Z bucket sizes itself (16 KB,
+//                   L2-resident), then moves its car ids to their next-hour buckets.
+// The bucket sizes ARE the parking histogram of the next hour.  The order of ids inside a
+// bucket is arbitrary (it depends on atomic arrival order) and does not matter: a car's draw
+// depends only on (seed, global car id, step) and integer counts are order-free.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 
 #include "../../include/cpm.h"
@@ -10,17 +28,421 @@
 
 namespace cpm {
 
+constexpr int kZoneBlock = 256;
+constexpr int kSortBlock = 1024;
+
+// ABL (diagnostic builds only, results wrong): 1 = no search, 2 = no Philox, 4 = no row staging
+template <bool TRAVEL, int BLOCK, int ABL>
+__global__ __launch_bounds__(BLOCK) void k_zone_sample(
+    const uint32_t *__restrict__ ids, const uint32_t *__restrict__ off, uint32_t *__restrict__ dest_out,
+    const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int64_t car_begin,
+    uint32_t step, uint64_t seed, unsigned long long *__restrict__ parking_t,
+    unsigned long long *__restrict__ driving_t, const double *__restrict__ dm, int T, int t,
+    unsigned long long *tt_sum)
+{
+    extern __shared__ double row[];  // Zp doubles: the CDF row of this origin zone
+    __shared__ uint32_t s_ndrive;
+    __shared__ unsigned long long s_tt;
+    const int z = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t b = off[z], e = off[z + 1];
+    if (tid == 0) {
+        parking_t[z] = e - b;  // every car present at hour t, drivers included (Appendix A-14)
+        s_ndrive = 0;
+        s_tt = 0;
+    }
+    if (e == b) return;  // driving_t[z] stays 0 (zeroed by the caller)
+    // stage the row: 16 B per lane, whole 128-B lines
+    const double2 *src = reinterpret_cast<const double2 *>(cdf_t + static_cast<size_t>(z) * Zp);
+    double2 *dst = reinterpret_cast<double2 *>(row);
+    if (!(ABL & 4))
+        for (int i = tid; i < Zp / 2; i += BLOCK) dst[i] = src[i];
+    const double pd = pdrive_t[z];
+    __syncthreads();
+    const double last = row[Z - 1];
+    uint32_t nd = 0;
+    long long tt = 0;
+    for (uint32_t s = b + tid; s < e; s += BLOCK) {
+        uint32_t id = ids[s];
+        uint64_t car = static_cast<uint64_t>(car_begin) + id;
+        double ub, uc;
+        if (ABL & 2) {
+            ub = (id * 2654435761u) * 0x1.0p-32;
+            uc = ((id ^ step) * 2246822519u) * 0x1.0p-32;
+        } else {
+            car_uniforms(seed, car, step, 0, ub, uc);
+        }
+        bool drive = ub <= pd;
+        uint32_t dest = z;
+        if (drive) {
+            if (ABL & 1) dest = static_cast<uint32_t>(uc * Z);
+            else if (last != 0.0) dest = static_cast<uint32_t>(lower_bound_row(row, Z, clamp_u(uc, last)));
+            if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest, seed, car, step);
+            ++nd;
+        }
+        dest_out[s] = dest | (drive ? kDriveBit : 0u);
+    }
+    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+    if ((tid & 63) == 0 && nd) atomicAdd(&s_ndrive, nd);
+    if (TRAVEL) {
+        for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
+        if ((tid & 63) == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        driving_t[z] = s_ndrive;
+        if (TRAVEL && s_tt) atomicAdd(tt_sum, s_tt);
+    }
+}
+
+// Wave-aggregated LDS atomics.  The slots of a chunk are ordered by origin zone and about half
+// the cars stay where they are, so within one wave-instruction dozens of lanes carry the SAME
+// key (their own zone, drive flag clear): plain LDS atomics on one address serialise (measured:
+// ~140 cycles per wave-instruction).  Lanes with the flag clear are therefore grouped by key with
+// ballots (at most two rounds: a wave's slots span one or two zones); one lane adds the group
+// size.  Drivers' keys are scattered over all zones and go one by one.
+__device__ __forceinline__ void wave_hist_add(uint32_t *bins, uint32_t keyflag, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = keyflag & kZoneMask;
+    bool agg = valid && !(keyflag & kDriveBit);
+    unsigned long long todo = __ballot(agg);
+    for (int it = 0; it < 2 && todo; ++it) {
+        int first = __ffsll(static_cast<long long>(todo)) - 1;
+        uint32_t k = __shfl(key, first, 64);
+        unsigned long long same = __ballot(agg && key == k) & todo;
+        if (lane == first) atomicAdd(&bins[k], static_cast<uint32_t>(__popcll(same)));
+        todo &= ~same;
+    }
+    bool single = valid && ((keyflag & kDriveBit) || ((todo >> lane) & 1ull));
+    if (single) atomicAdd(&bins[key], 1u);
+}
+
+__device__ __forceinline__ uint32_t wave_slot_take(uint32_t *pos, uint32_t keyflag, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = keyflag & kZoneMask;
+    bool agg = valid && !(keyflag & kDriveBit);
+    unsigned long long todo = __ballot(agg);
+    uint32_t p = 0;
+    for (int it = 0; it < 2 && todo; ++it) {
+        int first = __ffsll(static_cast<long long>(todo)) - 1;
+        uint32_t k = __shfl(key, first, 64);
+        unsigned long long same = __ballot(agg && key == k) & todo;
+        uint32_t b = 0;
+        if (lane == first) b = atomicAdd(&pos[k], static_cast<uint32_t>(__popcll(same)));
+        b = __shfl(b, first, 64);
+        if ((same >> lane) & 1ull) p = b + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+        todo &= ~same;
+    }
+    bool single = valid && ((keyflag & kDriveBit) || ((todo >> lane) & 1ull));
+    if (single) p = atomicAdd(&pos[key], 1u);
+    return p;
+}
+
+// counting sort pass 1.  key[i] & kZoneMask = bucket of slot i.  chunk is a multiple of 4 and
+// key is 16-B aligned: 16 B per lane per load, all of a thread's loads issued before its atomics.
+constexpr int kSortUnroll = 4;
+
+template <int ABL>
+__global__ __launch_bounds__(kSortBlock) void k_zone_hist(const uint32_t *__restrict__ key, int64_t n, int Z,
+                                                          int64_t chunk, uint32_t *__restrict__ cursor,
+                                                          uint32_t *__restrict__ base)
+{
+    extern __shared__ uint32_t bins[];  // Z
+    for (int z = threadIdx.x; z < Z; z += kSortBlock) bins[z] = 0;
+    __syncthreads();
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * chunk, i1 = min(i0 + chunk, n);
+    const int64_t n4 = (i1 > i0) ? (i1 - i0) / 4 : 0;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(key + i0);
+    for (int64_t j0 = 0; j0 < n4; j0 += kSortBlock * kSortUnroll) {  // wave-uniform trip count
+        const int64_t j = j0 + threadIdx.x;
+        uint4 v[kSortUnroll];
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u)
+            if (j + u * kSortBlock < n4) v[u] = k4[j + u * kSortBlock];
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u) {
+            const bool ok = j + u * kSortBlock < n4;
+            wave_hist_add(bins, v[u].x, ok);
+            wave_hist_add(bins, v[u].y, ok);
+            wave_hist_add(bins, v[u].z, ok);
+            wave_hist_add(bins, v[u].w, ok);
+        }
+    }
+    for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += kSortBlock) atomicAdd(&bins[key[i] & kZoneMask], 1u);
+    __syncthreads();
+    uint32_t *mybase = base + static_cast<size_t>(blockIdx.x) * Z;
+    for (int z = threadIdx.x; z < Z; z += kSortBlock) {
+        uint32_t c = bins[z];
+        mybase[z] = c ? atomicAdd(&cursor[z], c) : 0u;  // this block's range inside bucket z
+    }
+}
+
+// counting sort pass 2.  ids == nullptr: slot index is the car id (initial bucketing).
+template <int ABL>
+__global__ __launch_bounds__(kSortBlock) void k_zone_scatter(const uint32_t *__restrict__ key,
+                                                             const uint32_t *__restrict__ ids, int64_t n, int Z,
+                                                             int64_t chunk, const uint32_t *__restrict__ cursor,
+                                                             const uint32_t *__restrict__ base,
+                                                             uint32_t *__restrict__ ids_next,
+                                                             uint32_t *__restrict__ off_next)
+{
+    extern __shared__ uint32_t pos[];  // Z
+    __shared__ uint32_t wsum[kSortBlock / 64];
+    const int tid = threadIdx.x;
+    // exclusive scan of the Z bucket sizes, redone by every block (reads Z*4 B from L2)
+    const int per = (Z + kSortBlock - 1) / kSortBlock;
+    const int z0 = tid * per;
+    uint32_t mine = 0;
+    for (int k = 0; k < per; ++k)
+        if (z0 + k < Z) mine += cursor[z0 + k];
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    uint32_t run = wbase + incl - mine;
+    const uint32_t *mybase = base + static_cast<size_t>(blockIdx.x) * Z;
+    for (int k = 0; k < per; ++k) {
+        int z = z0 + k;
+        if (z < Z) {
+            pos[z] = run + mybase[z];
+            if (blockIdx.x == 0) off_next[z] = run;
+            run += cursor[z];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) off_next[Z] = static_cast<uint32_t>(n);
+    __syncthreads();
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * chunk, i1 = min(i0 + chunk, n);
+    const int64_t n4 = (i1 > i0) ? (i1 - i0) / 4 : 0;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(key + i0);
+    const uint4 *id4 = reinterpret_cast<const uint4 *>(ids ? ids + i0 : nullptr);
+    for (int64_t j0 = 0; j0 < n4; j0 += kSortBlock * kSortUnroll) {  // wave-uniform trip count
+        const int64_t j = j0 + tid;
+        uint4 v[kSortUnroll], c[kSortUnroll];
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u)
+            if (j + u * kSortBlock < n4) {
+                int64_t q = j + u * kSortBlock;
+                v[u] = k4[q];
+                if (ids) c[u] = id4[q];
+                else {
+                    uint32_t f = static_cast<uint32_t>(i0 + 4 * q);
+                    c[u] = make_uint4(f, f + 1, f + 2, f + 3);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < kSortUnroll; ++u) {
+            const bool ok = j + u * kSortBlock < n4;
+            uint32_t p0, p1, p2, p3;
+            if (ABL & 16) {
+                p0 = static_cast<uint32_t>(i0 + 4 * (j + u * kSortBlock));
+                p1 = p0 + 1; p2 = p0 + 2; p3 = p0 + 3;
+            } else {
+                p0 = wave_slot_take(pos, v[u].x, ok);
+                p1 = wave_slot_take(pos, v[u].y, ok);
+                p2 = wave_slot_take(pos, v[u].z, ok);
+                p3 = wave_slot_take(pos, v[u].w, ok);
+            }
+            if (ok) {
+                if (ABL & 8) {
+                    if (p0 + p1 + p2 + p3 == 0xdeadbeefu) ids_next[0] = c[u].x + c[u].y + c[u].z + c[u].w;
+                } else {
+                    ids_next[p0] = c[u].x;
+                    ids_next[p1] = c[u].y;
+                    ids_next[p2] = c[u].z;
+                    ids_next[p3] = c[u].w;
+                }
+            }
+        }
+    }
+    for (int64_t i = i0 + 4 * n4 + tid; i < i1; i += kSortBlock) {
+        uint32_t p = atomicAdd(&pos[key[i] & kZoneMask], 1u);
+        ids_next[p] = ids ? ids[i] : static_cast<uint32_t>(i);
+    }
+}
+
 struct ZoneWork {
     bool tables_dirty = true;
-    void release() {}
+    bool buckets0_valid = false;  // ids0/off0 describe the context's current car state
+    int block = 256;              // workgroup size of k_zone_sample (tuning knob)
+    int ablate = 0;               // diagnostic: see k_zone_sample ABL
+    int64_t n = 0;
+    int Z = 0, T = 0, nb = 0;
+    uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [n]
+    uint32_t *dest = nullptr;                                    // [n]
+    uint32_t *off0 = nullptr, *offA = nullptr, *offB = nullptr;  // [Z+1]
+    uint32_t *cursor = nullptr;                                  // [T+1][Z]
+    uint32_t *base = nullptr;                                    // [nb][Z]
+
+    void release()
+    {
+        for (uint32_t **p : {&ids0, &idsA, &idsB, &dest, &off0, &offA, &offB, &cursor, &base}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        n = 0;
+        buckets0_valid = false;
+    }
+
+    hipError_t ensure(int64_t n_, int Z_, int T_, int cu_count)
+    {
+        if (n_ == n && Z_ == Z && T_ == T && ids0) return hipSuccess;
+        release();
+        n = n_;
+        Z = Z_;
+        T = T_;
+        nb = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(cu_count, (n + 4095) / 4096)));
+        hipError_t e = hipSuccess;
+        auto alloc = [&](uint32_t **p, size_t words) {
+            if (e == hipSuccess) e = hipMalloc(p, sizeof(uint32_t) * std::max<size_t>(words, 1));
+        };
+        alloc(&ids0, n);
+        alloc(&idsA, n);
+        alloc(&idsB, n);
+        alloc(&dest, n);
+        alloc(&off0, Z + 1);
+        alloc(&offA, Z + 1);
+        alloc(&offB, Z + 1);
+        alloc(&cursor, static_cast<size_t>(T + 1) * Z);
+        alloc(&base, static_cast<size_t>(nb) * Z);
+        if (e != hipSuccess) release();
+        return e;
+    }
 };
 
-template <typename F1, typename F2>
-int32_t zone_resample(ZoneWork &, hipStream_t, const double *, const double *, int, int, int, int64_t, int64_t,
-                      const uint32_t *, uint64_t, bool, const double *, int64_t *, int, F1, F2, std::string &err)
+struct ZoneWork;
+inline size_t zone_sample_lds(int Zp) { return sizeof(double) * static_cast<size_t>(Zp); }
+
+// true when the zone path can run this problem (LDS row + sort bins must fit a CU's 160 KiB)
+inline bool zone_path_fits(int Zp) { return zone_sample_lds(Zp) + 64 <= 160 * 1024; }
+
+#define CPM_ZS_ARGS ids, off, w.dest, pd, cdf, Z, Zp, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum
+
+template <int BLOCK, int ABL>
+inline void launch_zone_sample_b(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
+                                 const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
+                                 uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
+                                 const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row)
 {
-    err = "CPM_KERNEL_ZONE_LDS is not built yet";
-    return CPM_ERR_STATE;
+    if (travel)
+        hipLaunchKernelGGL((k_zone_sample<true, BLOCK, ABL>), dim3(Z), dim3(BLOCK), lds_row, stream, CPM_ZS_ARGS);
+    else
+        hipLaunchKernelGGL((k_zone_sample<false, BLOCK, ABL>), dim3(Z), dim3(BLOCK), lds_row, stream, CPM_ZS_ARGS);
+}
+
+inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
+                               const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
+                               uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
+                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row);
+
+template <typename F1, typename F2>
+int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
+                      int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
+                      const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err)
+{
+    auto hip_fail = [&](hipError_t e, const char *what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
+    };
+    if (!zone_path_fits(Zp)) {
+        err = "CPM_KERNEL_ZONE_LDS: a CDF row of this many zones does not fit in LDS (use CPM_KERNEL_CAR)";
+        return CPM_ERR_ARG;
+    }
+    hipError_t e = w.ensure(n, Z, T, cu_count);
+    if (e != hipSuccess) return hip_fail(e, "zone workspace");
+    const size_t lds_row = zone_sample_lds(Zp), lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
+    if (w.tables_dirty) {  // LDS opt-in above 64 KiB, once per context / table size
+        if (lds_row > 64 * 1024) {
+            const void *fns[] = {reinterpret_cast<const void *>(k_zone_sample<false, 128, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 128, 0>),
+                                 reinterpret_cast<const void *>(k_zone_sample<false, 256, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 256, 0>),
+                                 reinterpret_cast<const void *>(k_zone_sample<false, 512, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 512, 0>),
+                                 reinterpret_cast<const void *>(k_zone_sample<false, 1024, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 1024, 0>)};
+            for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_row));
+        }
+        if (lds_bins > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_hist<0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_scatter<0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
+        }
+        w.tables_dirty = false;
+    }
+    const int64_t chunk = ((n + w.nb - 1) / w.nb + 3) / 4 * 4;  // multiple of 4: 16-B aligned chunks
+    const dim3 sgrid(static_cast<unsigned>(w.nb)), sblock(kSortBlock);
+    e = hipMemsetAsync(w.cursor, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
+    if (e != hipSuccess) return hip_fail(e, "memset cursor");
+    if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
+        uint32_t *cur0 = w.cursor + static_cast<size_t>(T) * Z;
+        hipLaunchKernelGGL(k_zone_hist<0>, sgrid, sblock, lds_bins, stream, d_zone0, n, Z, chunk, cur0, w.base);
+        hipLaunchKernelGGL(k_zone_scatter<0>, sgrid, sblock, lds_bins, stream, d_zone0, static_cast<const uint32_t *>(nullptr),
+                           n, Z, chunk, cur0, w.base, w.ids0, w.off0);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
+        w.buckets0_valid = true;
+    }
+    unsigned long long *parking = reinterpret_cast<unsigned long long *>(d_counts);
+    unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
+    unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
+    const uint32_t *ids = w.ids0, *off = w.off0;
+    for (int t = 0; t < T; ++t) {
+        const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
+        const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
+        uint32_t step = static_cast<uint32_t>(T - 1 + t);
+        prof_begin(t);
+        launch_zone_sample(w, stream, travel, ids, off, pd, cdf, Z, Zp, car_begin, step, seed,
+                           parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum,
+                           lds_row);
+        prof_end(t);
+        if (t + 1 < T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83)
+            uint32_t *cur = w.cursor + static_cast<size_t>(t) * Z;
+            uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
+            uint32_t *off_next = (t & 1) ? w.offB : w.offA;
+#define CPM_SORT_CALL(A)                                                                                      \
+    hipLaunchKernelGGL(k_zone_hist<A>, sgrid, sblock, lds_bins, stream, w.dest, n, Z, chunk, cur, w.base);   \
+    hipLaunchKernelGGL(k_zone_scatter<A>, sgrid, sblock, lds_bins, stream, w.dest, ids, n, Z, chunk, cur, w.base, ids_next, off_next)
+            switch (w.ablate & ~7) {
+            case 8: CPM_SORT_CALL(8); break;
+            case 16: CPM_SORT_CALL(16); break;
+            case 24: CPM_SORT_CALL(24); break;
+            default: CPM_SORT_CALL(0); break;
+            }
+            ids = ids_next;
+            off = off_next;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zone hour launch");
+    }
+    return CPM_OK;
+}
+
+#define CPM_ZS_CALL(B, A) \
+    launch_zone_sample_b<B, A>(w, stream, travel, ids, off, pd, cdf, Z, Zp, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, lds_row)
+
+inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
+                               const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
+                               uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
+                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row)
+{
+    if (w.ablate & 7) {  // diagnostic ablations, 256-thread form only
+        switch (w.ablate & 7) {
+        case 1: CPM_ZS_CALL(256, 1); break;
+        case 2: CPM_ZS_CALL(256, 2); break;
+        case 3: CPM_ZS_CALL(256, 3); break;
+        case 4: CPM_ZS_CALL(256, 4); break;
+        default: CPM_ZS_CALL(256, 7); break;
+        }
+        return;
+    }
+    switch (w.block) {
+    case 128: CPM_ZS_CALL(128, 0); break;
+    case 512: CPM_ZS_CALL(512, 0); break;
+    case 1024: CPM_ZS_CALL(1024, 0); break;
+    default: CPM_ZS_CALL(256, 0); break;
+    }
 }
 
 }  // namespace cpm

@@ -4,7 +4,7 @@ Cars are independent chains (src/resampling.jl:11-83 reads only car i's row), so
 cut into WORLD_SIZE contiguous ranges; every rank holds the full tables and samples its range
 with Philox keyed by the GLOBAL car id, which makes the summed histogram identical for every
 world size.  The only exchange on the path is ONE all-reduce(sum) of the integer tensor
-[parking | driving | travel-time q16] (2*T*Z+1 int64 words) before normalisation
+[parking | driving | travel-time q16 | status] (2*T*Z+2 int64 words) before normalisation
 (src/saveresults.jl:20) -- integer addition, so the result is order-free and bit-exact.
 """
 import torch
@@ -28,9 +28,12 @@ def allreduce_counts(counts):
 
 
 def split_counts(counts, Z, T):
-    """[2*T*Z+1] int64 -> (parking (Z,T), driving (Z,T) as Fortran-ordered views, sum_tt_q16)."""
+    """[2*T*Z+2] int64 -> (parking (Z,T), driving (Z,T) as Fortran-ordered views, sum_tt_q16).
+    Raises if the status word is set (fused-kernel rank overflow: repeat with another kernel)."""
     zt = Z * T
     flat = counts.detach().cpu().numpy()
+    if flat.size > 2 * zt + 1 and flat[2 * zt + 1] != 0:
+        raise RuntimeError("resample status != 0: fused zone kernel overflow, repeat with CPM_KERNEL_ZONE_LDS")
     parking = flat[:zt].reshape((Z, T), order="F")
     driving = flat[zt:2 * zt].reshape((Z, T), order="F")
     return parking, driving, int(flat[2 * zt])

@@ -139,12 +139,13 @@ class Sampler:
         return dict(parking=parking, driving=driving, sum_tt_q16=int(tt.value), state=state, trans=trans)
 
     def resample_dev(self, seed, d_counts_ptr, travel=False):
-        """Enqueue on the context's stream; d_counts_ptr = device address of int64[2*T*Z+1]."""
+        """Enqueue on the context's stream; d_counts_ptr = device address of int64[2*T*Z+2]
+        (parking | driving | sum_tt_q16 | status; status != 0 -> repeat with another kernel)."""
         flags = _lib.CPM_FLAG_TRAVEL if travel else 0
         _lib.check(self._L.cpm_resample_dev(self._h, int(seed), flags, C.c_void_p(int(d_counts_ptr))))
 
     def counts_words(self):
-        return 2 * self.T * self.Z + 1
+        return 2 * self.T * self.Z + 2
 
     def last_kernel_ms(self):
         buf = (C.c_float * 8192)()

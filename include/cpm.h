@@ -59,10 +59,14 @@ extern "C" {
 /* search kernels (cpm_set_option CPM_OPT_KERNEL) */
 #define CPM_KERNEL_AUTO 0
 #define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
-#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS */
+#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS (three launches per hour) */
+#define CPM_KERNEL_ZONE_FUSED 3 /* same, persistent workgroups + fused counting-sort histogram */
 
 #define CPM_OPT_KERNEL 1
 #define CPM_OPT_PROFILE 2       /* 1: bracket every hourly kernel with hipEvents */
+#define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
+#define CPM_OPT_ZONE_CPT 4      /* tuning: cars per thread in the fused zone sampler */
+#define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;
 
@@ -131,8 +135,12 @@ int32_t cpm_resample(cpm_ctx *ctx, uint64_t seed, uint32_t flags, int64_t *parki
 
 /* ---- device-resident forms for the host layer (torch tensors, RCCL) ----- */
 /* enqueue the fused resample on the context's stream and return without synchronising.
- * d_counts: DEVICE pointer to int64[2*T*Z + 1] = parking[T][Z] | driving[T][Z] | sum_tt_q16,
- * zeroed and filled by the call (ready for one all-reduce). */
+ * d_counts: DEVICE pointer to int64[2*T*Z + 2] = parking[T][Z] | driving[T][Z] | sum_tt_q16 |
+ * status, zeroed and filled by the call (ready for one all-reduce).  status != 0 (after the
+ * reduce: on any rank) means the fused zone kernel met a destination bucket it cannot index
+ * (more than 65535 drivers from one workgroup to one zone); the counts are then invalid and the
+ * caller repeats the step with CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR.  cpm_resample does this
+ * by itself. */
 int32_t cpm_resample_dev(cpm_ctx *ctx, uint64_t seed, uint32_t flags, void *d_counts);
 int32_t cpm_solve_ivp_async(cpm_ctx *ctx, uint64_t seed);
 /* procedural synthetic tables of SURVEY.md 8(d), generated on device (bench inputs):
