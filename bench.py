@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--zones", type=int, default=4096)
     ap.add_argument("--cars-per-zone", type=int, default=1000, help="per GPU (weak scaling)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 3 zone_fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -150,7 +150,7 @@ def main():
             "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
-                       "kernel": {0: "auto", 1: "car", 2: "zone_lds"}[args.kernel],
+                       "kernel": {0: "auto (zone_lds)", 1: "car", 2: "zone_lds", 3: "zone_fused"}[args.kernel],
                        "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
                        "device": cpm.device_info(local_rank)["name"]},

@@ -18,6 +18,7 @@ SYMBOLS = [
     "cpm_build_p_drive", "cpm_build_p_dest", "cpm_get_p_drive", "cpm_get_cdf_row", "cpm_init_states",
     "cpm_set_state", "cpm_get_state", "cpm_solve_ivp", "cpm_resample", "cpm_resample_dev",
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
+    "cpm_debug_cycles",
 ]
 
 CPM_FLAG_TRAVEL = 1
@@ -80,6 +81,7 @@ def load():
     L.cpm_synth_tables.argtypes = [vp, u64]
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
+    L.cpm_debug_cycles.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("cpm_last_error",):

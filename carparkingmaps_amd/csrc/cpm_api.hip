@@ -144,9 +144,12 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
     return CPM_OK;
 }
 
+// AUTO: the zone-bucketed LDS path when a CDF row fits in LDS and there are enough cars per zone
+// to amortise streaming every row once per hour; otherwise one thread per car.
 int pick_kernel(const cpm_ctx *c)
 {
     if (c->kernel != CPM_KERNEL_AUTO) return c->kernel;
+    if (cpm::zone_path_fits(c->Zp) && c->n >= 32 * c->Z && c->n < (int64_t(1) << 32)) return CPM_KERNEL_ZONE_LDS;
     return CPM_KERNEL_CAR;
 }
 
@@ -256,6 +259,12 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
+    if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::zone_path_fits(c->Zp)) {
+        int32_t rc = cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                        static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr,
+                                        c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
+        return rc;
+    }
     // src/solveinitialvalueproblem.jl:8 : t = 1:(T-1), state update unconditional (:53)
     for (int t = 0; t < c->T - 1; ++t) {
         int32_t rc = launch_step_car(c, c->d_zone0, c->d_ztmp, t, static_cast<uint32_t>(t), seed, false, nullptr);
@@ -682,6 +691,17 @@ int32_t cpm_last_kernel_ms(cpm_ctx *c, float *ms_out, int32_t cap, int32_t *n_ou
     int n = std::min<int>(c->n_prof, cap);
     for (int k = 0; k < n; ++k) HIP_TRY(hipEventElapsedTime(&ms_out[k], c->ev[2 * k], c->ev[2 * k + 1]));
     *n_out = n;
+    return CPM_OK;
+}
+
+int32_t cpm_debug_cycles(cpm_ctx *c, uint64_t *out8)
+{
+    CTX_TRY(c);
+    if (!out8) return fail(CPM_ERR_ARG, "null out8");
+    if (!c->zw2.dbg) return fail(CPM_ERR_STATE, "no diagnostic buffer");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out8, c->zw2.dbg, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->zw2.dbg, 0, sizeof(uint64_t) * 8));
     return CPM_OK;
 }
 

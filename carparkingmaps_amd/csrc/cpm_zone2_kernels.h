@@ -37,6 +37,11 @@
 
 namespace cpm {
 
+// Ticket counters are replicated kRep times on separate cache lines (workgroup b uses replica
+// b % kRep): atomics on one line are served one after the other at the memory side (~50 ns each),
+// so 683 workgroups ticketing the same 128 lines cost ~35 us; with 8 replicas ~4 us.
+constexpr int kRep = 8;
+constexpr int kMaxZonesPerWg = 64;
 constexpr int kDestBits = 16;  // D key = dest | rank << 16 : needs Z <= 65536 and rank < 65536
 constexpr uint32_t kDestMask = (1u << kDestBits) - 1u;
 
@@ -57,8 +62,9 @@ struct Zone2Args {
     uint32_t *nS_next;       // [Z]
     uint2 *D;                // drivers (id, dest | rank << 16), workgroup b at [Ln[zb0], ...)
     uint32_t *nd;            // [gridDim.x] drivers per workgroup
-    uint32_t *cursor;        // [Z] arrivals per zone of the next hour (ticket counters)
+    uint32_t *cursor;        // [kRep][Z] arrivals per zone of the next hour (ticket counters)
     uint32_t *base;          // [gridDim.x][Z] this workgroup's range inside each arrival bucket
+    unsigned long long *dbg;     // diagnostic (ABL & 4): per-workgroup cycle sums of the kernel's segments
     unsigned long long *status;  // counts word 2*T*Z+1: bit 0 set when a rank does not fit 16 bits (host falls back)
     // results
     unsigned long long *parking_t, *driving_t, *tt_sum;
@@ -98,6 +104,8 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
     extern __shared__ double lds[];  // row tree: 2^H doubles, then bins: Z u32
     __shared__ uint32_t s_cntS, s_cntD, s_drv;
     __shared__ unsigned long long s_tt;
+    __shared__ uint32_t mL[kMaxZonesPerWg + 1], mNS[kMaxZonesPerWg], mOffA[kMaxZonesPerWg + 1], mLn[kMaxZonesPerWg + 1];
+    __shared__ long long mThr[kMaxZonesPerWg];
     const int Z = a.Z, Zp = a.Zp, H = a.H;
     const int P = 1 << H;
     double *row = lds;
@@ -122,43 +130,65 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
         s_cntD = 0;
         s_tt = 0;
     }
-    const uint32_t dlo = LAST ? 0u : a.Ln[zb0];
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    auto load_row = [&](double2(&pc)[NP], int z) {
-        const double2 *src = reinterpret_cast<const double2 *>(a.cdf_t + static_cast<size_t>(z) * Zp);
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-            int j = tid + m * BLOCK;
-            if (2 * j < Zp) pc[m] = src[j];
+    // Zone metadata of this workgroup's range -> LDS, once.  Read through LDS the per-zone
+    // scalars cost no vector-memory operation, so nothing in the zone loop waits on vmcnt except
+    // the one counted wait for the row registers.
+    const int nzw = zb1 - zb0;
+    for (int i = tid; i <= nzw; i += BLOCK) {
+        mL[i] = a.L[zb0 + i];
+        mOffA[i] = a.offA[zb0 + i];
+        mLn[i] = LAST ? 0u : a.Ln[zb0 + i];
+        if (i < nzw) {
+            mNS[i] = a.nS[zb0 + i];
+            mThr[i] = bernoulli_threshold(a.pdrive_t[zb0 + i]);
         }
-    };
-    auto load_ids = [&](int z, uint32_t(&ids)[CPT]) {
-        const uint32_t sBeg = a.L[z], nS = a.nS[z];
-        const uint32_t aBeg = a.offA[z], nz = nS + (a.offA[z + 1] - aBeg);
+    }
+    __syncthreads();  // LDS init + metadata visible
+
+    // Prefetch of zone (zb0 + zi): its CPT car ids per thread, then its row, two zones ahead.
+    // Every load is unconditional and branch-free (indices clamped into range): the number of
+    // vector-memory operations per step is then the same on every path, and the compiler's
+    // in-order vmcnt wait for one zone's registers leaves the next zone's loads in flight.
+    auto prefetch = [&](double2(&pc)[NP], uint32_t(&ids)[CPT], int zi) {
+        zi = min(zi, nzw - 1);
+        const uint32_t sBeg = mL[zi], nS = mNS[zi], aBeg = mOffA[zi];
+        const uint32_t nz = nS + (mOffA[zi + 1] - aBeg);
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const uint32_t q = tid + c * BLOCK;
-            ids[c] = 0;
-            if (q < nz) ids[c] = (q < nS) ? a.S[sBeg + q] : a.A[aBeg + (q - nS)];
+            const uint32_t q = min(static_cast<uint32_t>(tid + c * BLOCK), nz ? nz - 1 : 0u);
+            const uint32_t *p = (q < nS) ? a.S + sBeg + q : a.A + (nz ? aBeg + (q - nS) : 0u);
+            ids[c] = *p;
+        }
+        const double2 *src = reinterpret_cast<const double2 *>(a.cdf_t + static_cast<size_t>(zb0 + zi) * Zp);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) pc[m] = src[min(tid + m * BLOCK, Zp / 2 - 1)];
+    };
+    double2 pieceA[NP], pieceB[NP];
+    uint32_t idsA[CPT], idsB[CPT];
+    prefetch(pieceA, idsA, 0);
+    prefetch(pieceB, idsB, 1);
+
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = (ABL & 4) ? clock64() : 0;
+    auto stamp = [&](int k) {
+        if (ABL & 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tn = clock64();
+            __builtin_amdgcn_sched_barrier(0);
+            seg[k] += tn - tprev;
+            tprev = tn;
         }
     };
-
-    // Rows are requested two zones ahead (two register sets), car ids one zone ahead, and in
-    // that order: vmcnt retires in order, so a wait for the ids never drains a younger row.
-    double2 pieceA[NP], pieceB[NP];
-    uint32_t cur[CPT], nxt[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) nxt[c] = 0;
-    load_ids(zb0, cur);
-    load_row(pieceA, zb0);
-    if (zb0 + 1 < zb1) load_row(pieceB, zb0 + 1);
-    __syncthreads();  // LDS init visible
-
-    auto step = [&](double2(&pc)[NP], int z) {
-        const uint32_t sBeg = a.L[z], nS = a.nS[z];
-        const uint32_t aBeg = a.offA[z], nz = nS + (a.offA[z + 1] - aBeg);
-        const long long thr = bernoulli_threshold(a.pdrive_t[z]);
+    const uint32_t dlo = mLn[0];
+    auto step = [&](double2(&pc)[NP], uint32_t(&ids)[CPT], int z) {
+        stamp(0);
+        const int zi = z - zb0;
+        const uint32_t sBeg = mL[zi], nS = mNS[zi];
+        const uint32_t aBeg = mOffA[zi], nz = nS + (mOffA[zi + 1] - aBeg);
+        const long long thr = mThr[zi];
+        uint32_t cur[CPT];
         // registers -> LDS tree (breadth-first permutation); the barrier that closed the previous
         // zone guarantees nobody still searches the old tree
 #pragma unroll
@@ -170,15 +200,18 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
                 if (e + 1 < static_cast<uint32_t>(Z)) row[eytz_pos(e + 1, Z, H)] = pc[m].y;
             }
         }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) cur[c] = ids[c];
         if (tid == 0) {
             s_cntS = 0;
             s_drv = 0;
         }
-        if (z + 1 < zb1) load_ids(z + 1, nxt);
-        if (z + 2 < zb1) load_row(pc, z + 2);
+        stamp(1);  // wait for the row registers + tree write
+        prefetch(pc, ids, zi + 2);
         __syncthreads();  // tree complete
+        stamp(2);  // prefetch issue + barrier
         const double last = row[0];
-        const uint32_t sOut = LAST ? 0u : a.Ln[z];
+        const uint32_t sOut = mLn[zi];
         long long tt = 0;
         uint32_t ndrv = 0;
 
@@ -222,6 +255,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
             for (int c = 0; c < CPT; ++c)
                 if (drive[c] && last != 0.0) dest[c] = eytz_decode(i[c], Z, H);
         }
+        stamp(3);  // Philox + Bernoulli + tree walks
         // compaction: one LDS reservation per wave for all CPT cars
         unsigned long long mD[CPT], mS[CPT];
         uint32_t totS = 0, totD = 0;
@@ -261,6 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
                     tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + cur[c],
                                           a.step);
         }
+        stamp(4);  // compaction, rank, stores
         // ---- zones with more than CPT*BLOCK cars (wave-uniform trip count) ------------------
         for (uint32_t q0 = CPT * BLOCK; q0 < nz; q0 += BLOCK) {
             const uint32_t q = q0 + tid;
@@ -302,21 +337,28 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
             for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
             if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
         }
+        stamp(5);  // overflow rounds + reductions
         __syncthreads();  // counters final; nobody still reads the tree
+        stamp(6);  // closing barrier
         if (tid == 0) {
             a.parking_t[z] = nz;  // every car present, drivers included (Appendix A-14)
             a.driving_t[z] = s_drv;
             if (!LAST) a.nS_next[z] = nz - s_drv;
         }
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) cur[c] = nxt[c];
     };
     for (int z = zb0; z < zb1; z += 2) {
-        step(pieceA, z);
-        if (z + 1 < zb1) step(pieceB, z + 1);
+        step(pieceA, idsA, z);
+        if (z + 1 < zb1) step(pieceB, idsB, z + 1);
     }
     if (TRAVEL && tid == 0 && s_tt) atomicAdd(a.tt_sum, s_tt);
-    if (LAST) return;
+    auto flush_stamps = [&]() {
+        if ((ABL & 4) && a.dbg && lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg[k], seg[k]);
+    };
+    if (LAST) {
+        flush_stamps();
+        return;
+    }
     if (tid == 0) a.nd[blockIdx.x] = s_cntD;
     // ticket: reserve this workgroup's range in every arrival bucket; all atomics of a thread
     // are issued before any result is used (one round trip instead of Z/BLOCK)
@@ -330,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
             r[k] = 0;
             if (z < Z) {
                 uint32_t c = bins[z];
-                if (c) r[k] = atomicAdd(&a.cursor[z], c);
+                if (c) r[k] = atomicAdd(&a.cursor[static_cast<size_t>(blockIdx.x % kRep) * Z + z], c);
             }
         }
 #pragma unroll
@@ -339,12 +381,16 @@ __global__ __launch_bounds__(BLOCK) void k_zone2_sample(Zone2Args a)
             if (z < Z) mybase[z] = r[k];
         }
     }
+    stamp(7);  // ticket
+    flush_stamps();
 }
 
-// Scatter of the drivers: no atomics.  Every block scans the Z arrival counts (-> offA of the
-// next hour, kept in LDS) and the Z zone sizes (-> layout L of the hour after); block 0 publishes
-// both.  Block g then moves the drivers of the sampler workgroups [g*wgs_per_blk, ...).
+// Scatter of the drivers: no atomics.  Block (r, j) moves the drivers of the sampler workgroups
+// b with b % kRep == r.  Every block sums the kRep ticket replicas per zone, scans the Z arrival
+// counts (-> offA of the next hour) and the Z zone sizes (-> layout L of the hour after); block 0
+// publishes both.  position = offA[dest] + (replicas below r)[dest] + base[b][dest] + rank.
 constexpr int kScatBlock = 1024;
+constexpr int kScatPerMax = 16;  // zones per thread in the scan: Z <= 16384
 
 __global__ __launch_bounds__(kScatBlock) void k_zone2_scatter(const uint2 *__restrict__ D, const uint32_t *__restrict__ Lcur,
                                                               const uint32_t *__restrict__ nd, int zones_per_wg, int nwg,
@@ -353,18 +399,35 @@ __global__ __launch_bounds__(kScatBlock) void k_zone2_scatter(const uint2 *__res
                                                               const uint32_t *__restrict__ base, uint32_t *__restrict__ A_next,
                                                               uint32_t *__restrict__ offA_next, uint32_t *__restrict__ L_next)
 {
-    extern __shared__ uint32_t offA[];  // Z
+    extern __shared__ uint32_t offR[];  // Z: start of replica r's range inside every arrival bucket
     __shared__ uint32_t wsumA[kScatBlock / 64], wsumT[kScatBlock / 64];
     const int tid = threadIdx.x;
+    const int rep = blockIdx.x % kRep, jblk = blockIdx.x / kRep;
     const int per = (Z + kScatBlock - 1) / kScatBlock;
     const int z0 = tid * per;
-    uint32_t mineA = 0, mineT = 0;
-    for (int k = 0; k < per; ++k)
-        if (z0 + k < Z) {
-            uint32_t c = cursor[z0 + k];
-            mineA += c;
-            mineT += c + nS_next[z0 + k];
+    // all loads first (independent), then the arithmetic: one memory round trip, not per*kRep
+    uint32_t tot[kScatPerMax], pre[kScatPerMax], ns[kScatPerMax];
+#pragma unroll
+    for (int k = 0; k < kScatPerMax; ++k) {
+        tot[k] = 0;
+        pre[k] = 0;
+        ns[k] = (k < per && z0 + k < Z) ? nS_next[z0 + k] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kRep; ++r) {
+#pragma unroll
+        for (int k = 0; k < kScatPerMax; ++k) {
+            uint32_t c = (k < per && z0 + k < Z) ? cursor[static_cast<size_t>(r) * Z + z0 + k] : 0u;
+            tot[k] += c;
+            if (r < rep) pre[k] += c;
         }
+    }
+    uint32_t mineA = 0, mineT = 0;
+#pragma unroll
+    for (int k = 0; k < kScatPerMax; ++k) {
+        mineA += tot[k];
+        mineT += tot[k] + ns[k];
+    }
     uint32_t inclA = mineA, inclT = mineT;
     for (int o = 1; o < 64; o <<= 1) {
         uint32_t va = __shfl_up(inclA, o, 64), vt = __shfl_up(inclT, o, 64);
@@ -379,26 +442,28 @@ __global__ __launch_bounds__(kScatBlock) void k_zone2_scatter(const uint2 *__res
     }
     __syncthreads();
     uint32_t wa = 0, wt = 0, totA = 0, totT = 0;
+#pragma unroll
     for (int w = 0; w < kScatBlock / 64; ++w) {
+        uint32_t sa = wsumA[w], st = wsumT[w];
         if (w < (tid >> 6)) {
-            wa += wsumA[w];
-            wt += wsumT[w];
+            wa += sa;
+            wt += st;
         }
-        totA += wsumA[w];
-        totT += wsumT[w];
+        totA += sa;
+        totT += st;
     }
     uint32_t runA = wa + inclA - mineA, runT = wt + inclT - mineT;
-    for (int k = 0; k < per; ++k) {
+#pragma unroll
+    for (int k = 0; k < kScatPerMax; ++k) {
         int z = z0 + k;
-        if (z < Z) {
-            uint32_t c = cursor[z];
-            offA[z] = runA;
+        if (k < per && z < Z) {
+            offR[z] = runA + pre[k];
             if (blockIdx.x == 0) {
                 offA_next[z] = runA;
                 L_next[z] = runT;
             }
-            runA += c;
-            runT += c + nS_next[z];
+            runA += tot[k];
+            runT += tot[k] + ns[k];
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -406,8 +471,10 @@ __global__ __launch_bounds__(kScatBlock) void k_zone2_scatter(const uint2 *__res
         L_next[Z] = totT;
     }
     __syncthreads();
-    const int b0 = blockIdx.x * wgs_per_blk, b1 = min(b0 + wgs_per_blk, nwg);
-    for (int b = b0; b < b1; ++b) {
+    // sampler workgroups of replica rep: b = rep + kRep * i, i in [jblk*wgs_per_blk, ...)
+    for (int i = jblk * wgs_per_blk; i < (jblk + 1) * wgs_per_blk; ++i) {
+        const int b = rep + kRep * i;
+        if (b >= nwg) break;
         const uint32_t n = nd[b];
         const uint2 *src = D + Lcur[min(b * zones_per_wg, Z)];
         const uint32_t *bb = base + static_cast<size_t>(b) * Z;
@@ -417,18 +484,18 @@ __global__ __launch_bounds__(kScatBlock) void k_zone2_scatter(const uint2 *__res
             uint32_t g[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                uint32_t i = i0 + tid + u * kScatBlock;
-                if (i < n) v[u] = src[i];
+                uint32_t q = i0 + tid + u * kScatBlock;
+                if (q < n) v[u] = src[q];
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                uint32_t i = i0 + tid + u * kScatBlock;
-                if (i < n) g[u] = bb[v[u].y & kDestMask];
+                uint32_t q = i0 + tid + u * kScatBlock;
+                if (q < n) g[u] = bb[v[u].y & kDestMask];
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                uint32_t i = i0 + tid + u * kScatBlock;
-                if (i < n) A_next[offA[v[u].y & kDestMask] + g[u] + (v[u].y >> kDestBits)] = v[u].x;
+                uint32_t q = i0 + tid + u * kScatBlock;
+                if (q < n) A_next[offR[v[u].y & kDestMask] + g[u] + (v[u].y >> kDestBits)] = v[u].x;
             }
         }
     }
@@ -446,10 +513,11 @@ struct Zone2Work {
     uint32_t *nS[2] = {nullptr, nullptr};  // [Z]
     uint32_t *nS0 = nullptr;               // [Z] zeros
     uint32_t *offA = nullptr, *offA0 = nullptr;  // [Z+1]
-    uint32_t *cursor = nullptr;            // [T+1][Z]
+    uint32_t *cursor = nullptr;            // [T][kRep][Z] ticket counters, then [Z] for the initial bucketing
     uint32_t *base = nullptr;              // [nwg][Z]
     uint32_t *nd = nullptr;                // [nwg]
     uint32_t *initbase = nullptr;          // [nb0][Z] ticket bases of the initial bucketing
+    unsigned long long *dbg = nullptr;     // [8] diagnostic cycle sums
     int nb0 = 0;
 
     void release()
@@ -461,6 +529,8 @@ struct Zone2Work {
         }
         if (D) (void)hipFree(D);
         D = nullptr;
+        if (dbg) (void)hipFree(dbg);
+        dbg = nullptr;
         n = 0;
         buckets0_valid = false;
     }
@@ -493,12 +563,14 @@ struct Zone2Work {
         alloc(&nS0, Z);
         alloc(&offA, Z + 1);
         alloc(&offA0, Z + 1);
-        alloc(&cursor, static_cast<size_t>(T + 1) * Z);
+        alloc(&cursor, (static_cast<size_t>(T) * kRep + 1) * Z);
         alloc(&base, static_cast<size_t>(nwg) * Z);
         alloc(&nd, nwg);
         alloc(&initbase, static_cast<size_t>(nb0) * Z);
         if (e == hipSuccess) e = hipMalloc(&D, sizeof(uint2) * std::max<int64_t>(n, 1));
         if (e == hipSuccess) e = hipMemset(nS0, 0, sizeof(uint32_t) * Z);
+        if (e == hipSuccess) e = hipMalloc(&dbg, sizeof(unsigned long long) * 8);
+        if (e == hipSuccess) e = hipMemset(dbg, 0, sizeof(unsigned long long) * 8);
         if (e != hipSuccess) release();
         return e;
     }
@@ -512,7 +584,10 @@ inline int zone2_tree_height(int Z)
 }
 
 inline size_t zone2_sample_lds(int Z) { return sizeof(double) * (size_t(1) << zone2_tree_height(Z)) + sizeof(uint32_t) * Z; }
-inline bool zone2_path_fits(int Z) { return Z <= (1 << kDestBits) && zone2_sample_lds(Z) + 256 <= 160 * 1024; }
+inline bool zone2_path_fits(int Z)
+{
+    return Z <= (1 << kDestBits) && Z <= kScatBlock * kScatPerMax && zone2_sample_lds(Z) + 256 <= 160 * 1024;
+}
 
 template <bool TRAVEL, bool LAST, int BLOCK, int NP, int CPT, int ABL>
 inline void zone2_launch_one(const Zone2Args &a, int nwg, size_t lds, hipStream_t stream)
@@ -550,25 +625,22 @@ inline void zone2_launch_tl(const Zone2Args &a, bool travel, bool last, int nwg,
 
 inline void zone2_launch(const Zone2Work &w, const Zone2Args &a, bool travel, bool last, size_t lds, hipStream_t stream)
 {
-    if (w.ablate & 3) {  // diagnostic builds, one geometry only
-        switch (w.ablate & 3) {
-        case 1: zone2_launch_tl<512, 3, 1>(a, travel, last, w.nwg, lds, stream); break;
-        case 2: zone2_launch_tl<512, 3, 2>(a, travel, last, w.nwg, lds, stream); break;
-        default: zone2_launch_tl<512, 3, 3>(a, travel, last, w.nwg, lds, stream); break;
+    // diagnostic instantiations (ABL 1/2/3: no search / no Philox; 4: in-kernel stamps) are built only
+    // with -DCPM_DIAGNOSTIC; see tools/kbench.py
+#ifdef CPM_DIAGNOSTIC
+    if (w.ablate & 7) {
+        switch (w.ablate & 7) {
+        case 3: zone2_launch_tl<512, 2, 3>(a, travel, last, w.nwg, lds, stream); break;
+        default: zone2_launch_tl<512, 2, 4>(a, travel, last, w.nwg, lds, stream); break;
         }
         return;
     }
-    if (w.block == 1024) {
-        if (w.cpt == 1) zone2_launch_tl<1024, 1, 0>(a, travel, last, w.nwg, lds, stream);
-        else zone2_launch_tl<1024, 2, 0>(a, travel, last, w.nwg, lds, stream);
-    } else if (w.block == 256) {
-        if (w.cpt <= 4) zone2_launch_tl<256, 4, 0>(a, travel, last, w.nwg, lds, stream);
-        else zone2_launch_tl<256, 6, 0>(a, travel, last, w.nwg, lds, stream);
-    } else {
-        if (w.cpt == 2) zone2_launch_tl<512, 2, 0>(a, travel, last, w.nwg, lds, stream);
-        else if (w.cpt == 4) zone2_launch_tl<512, 4, 0>(a, travel, last, w.nwg, lds, stream);
-        else zone2_launch_tl<512, 3, 0>(a, travel, last, w.nwg, lds, stream);
+    if (w.cpt == 3) {
+        zone2_launch_tl<512, 3, 0>(a, travel, last, w.nwg, lds, stream);
+        return;
     }
+#endif
+    zone2_launch_tl<512, 2, 0>(a, travel, last, w.nwg, lds, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -592,11 +664,15 @@ int32_t zone2_resample(Zone2Work &w, hipStream_t stream, const double *d_pdrive,
         return CPM_ERR_ARG;
     }
     const size_t lds = zone2_sample_lds(Z) + 16, lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
-    const int blk = (w.block == 1024) ? 1024 : (w.block == 256 ? 256 : 512);
+    const int blk = 512;
     int wg_per_cu = std::max<int>(1, static_cast<int>((160 * 1024 - 512) / (lds + 64)));
     wg_per_cu = std::min(wg_per_cu, 2048 / blk);
     hipError_t e = w.ensure(n, Z, T, cu_count, wg_per_cu);
     if (e != hipSuccess) return hip_fail(e, "zone workspace");
+    if (w.zones_per_wg > kMaxZonesPerWg) {
+        err = "zone path: too many zones per workgroup for this device";
+        return CPM_ERR_ARG;
+    }
     if (!w.attrs_set) {
         if (lds_bins > 64 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_hist<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -608,11 +684,11 @@ int32_t zone2_resample(Zone2Work &w, hipStream_t stream, const double *d_pdrive,
         }
         w.attrs_set = true;
     }
-    e = hipMemsetAsync(w.cursor, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
+    e = hipMemsetAsync(w.cursor, 0, sizeof(uint32_t) * (static_cast<size_t>(T) * kRep + 1) * Z, stream);
     if (e != hipSuccess) return hip_fail(e, "memset cursor");
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         const int64_t chunk = ((n + w.nb0 - 1) / w.nb0 + 3) / 4 * 4;
-        uint32_t *cur0 = w.cursor + static_cast<size_t>(T) * Z;
+        uint32_t *cur0 = w.cursor + static_cast<size_t>(T) * kRep * Z;
         hipLaunchKernelGGL(k_zone_hist<0>, dim3(w.nb0), dim3(kSortBlock), lds_bins, stream, d_zone0, n, Z, chunk, cur0, w.initbase);
         hipLaunchKernelGGL(k_zone_scatter<0>, dim3(w.nb0), dim3(kSortBlock), lds_bins, stream, d_zone0,
                            static_cast<const uint32_t *>(nullptr), n, Z, chunk, cur0, w.initbase, w.A0, w.offA0);
@@ -621,14 +697,18 @@ int32_t zone2_resample(Zone2Work &w, hipStream_t stream, const double *d_pdrive,
     }
     unsigned long long *parking = reinterpret_cast<unsigned long long *>(d_counts);
     unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
-    const int scat_blocks = std::max(1, std::min(w.nwg, cu_count));
-    const int wgs_per_blk = (w.nwg + scat_blocks - 1) / scat_blocks;
+    // scatter grid: kRep replicas x blocks per replica; block (r, j) takes wgs_per_blk workgroups of replica r
+    const int wg_per_rep = (w.nwg + kRep - 1) / kRep;
+    const int blk_per_rep = std::max(1, std::min(wg_per_rep, std::max(1, cu_count / kRep)));
+    const int wgs_per_blk = (wg_per_rep + blk_per_rep - 1) / blk_per_rep;
+    const int scat_grid = kRep * ((wg_per_rep + wgs_per_blk - 1) / wgs_per_blk);
     Zone2Args a;
     a.dm = d_dm;
     a.D = w.D;
     a.nd = w.nd;
     a.base = w.base;
     a.status = parking + 2 * static_cast<size_t>(T) * Z + 1;
+    a.dbg = w.dbg;
     a.tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     a.Z = Z;
     a.Zp = Zp;
@@ -645,7 +725,7 @@ int32_t zone2_resample(Zone2Work &w, hipStream_t stream, const double *d_pdrive,
         a.step = static_cast<uint32_t>(T - 1 + t);
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
-        a.cursor = w.cursor + static_cast<size_t>(t) * Z;
+        a.cursor = w.cursor + static_cast<size_t>(t) * kRep * Z;
         if (t == 0) {
             a.S = w.S[1];  // empty: nS0 is all zero
             a.nS = w.nS0;
@@ -667,7 +747,7 @@ int32_t zone2_resample(Zone2Work &w, hipStream_t stream, const double *d_pdrive,
         zone2_launch(w, a, travel, last, lds, stream);
         prof_end(t);
         if (!last)
-            hipLaunchKernelGGL(k_zone2_scatter, dim3((w.nwg + wgs_per_blk - 1) / wgs_per_blk), dim3(kScatBlock), lds_bins, stream,
+            hipLaunchKernelGGL(k_zone2_scatter, dim3(scat_grid), dim3(kScatBlock), lds_bins, stream,
                                w.D, a.Ln, w.nd, w.zones_per_wg, w.nwg, wgs_per_blk, Z, a.cursor, a.nS_next, w.base, w.A, w.offA,
                                w.L[t & 1]);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zone hour launch");

@@ -267,10 +267,17 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_scatter(const uint32_t *__r
     }
 }
 
+// car-indexed state from the buckets: zone0[id] = zone of the bucket holding id
+__global__ void k_zone_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ off, uint32_t *__restrict__ zone0)
+{
+    const uint32_t z = blockIdx.x;
+    for (uint32_t s = off[z] + threadIdx.x; s < off[z + 1]; s += blockDim.x) zone0[ids[s]] = z;
+}
+
 struct ZoneWork {
     bool tables_dirty = true;
     bool buckets0_valid = false;  // ids0/off0 describe the context's current car state
-    int block = 256;              // workgroup size of k_zone_sample (tuning knob)
+    int block = 512;              // workgroup size of k_zone_sample (tuning knob; 512 measured best at Z = 4096)
     int ablate = 0;               // diagnostic: see k_zone_sample ABL
     int64_t n = 0;
     int Z = 0, T = 0, nb = 0;
@@ -341,10 +348,15 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
                                uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
                                const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row);
 
+// ivp == false: the T-hour resample from the state in d_zone0 (left unchanged); counts -> d_counts.
+// ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps
+//               0..T-2, every transition applied; the final buckets become the cached bucketing of
+//               the new state and are written back car-indexed into d_zone0_out.  d_counts is scratch.
 template <typename F1, typename F2>
 int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
                       int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
-                      const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err)
+                      const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err,
+                      bool ivp = false, uint32_t *d_zone0_out = nullptr)
 {
     auto hip_fail = [&](hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -389,32 +401,40 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
     unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
     unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     const uint32_t *ids = w.ids0, *off = w.off0;
-    for (int t = 0; t < T; ++t) {
+    const int hours = ivp ? T - 1 : T;
+    for (int t = 0; t < hours; ++t) {
         const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
         const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
-        uint32_t step = static_cast<uint32_t>(T - 1 + t);
+        uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
         prof_begin(t);
         launch_zone_sample(w, stream, travel, ids, off, pd, cdf, Z, Zp, car_begin, step, seed,
                            parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum,
                            lds_row);
         prof_end(t);
-        if (t + 1 < T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83)
+        if (ivp || t + 1 < T) {  // resampling: hour T's transition is sampled but never applied (src/resampling.jl:81-83)
             uint32_t *cur = w.cursor + static_cast<size_t>(t) * Z;
             uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
             uint32_t *off_next = (t & 1) ? w.offB : w.offA;
-#define CPM_SORT_CALL(A)                                                                                      \
-    hipLaunchKernelGGL(k_zone_hist<A>, sgrid, sblock, lds_bins, stream, w.dest, n, Z, chunk, cur, w.base);   \
-    hipLaunchKernelGGL(k_zone_scatter<A>, sgrid, sblock, lds_bins, stream, w.dest, ids, n, Z, chunk, cur, w.base, ids_next, off_next)
-            switch (w.ablate & ~7) {
-            case 8: CPM_SORT_CALL(8); break;
-            case 16: CPM_SORT_CALL(16); break;
-            case 24: CPM_SORT_CALL(24); break;
-            default: CPM_SORT_CALL(0); break;
-            }
+            hipLaunchKernelGGL(k_zone_hist<0>, sgrid, sblock, lds_bins, stream, w.dest, n, Z, chunk, cur, w.base);
+            hipLaunchKernelGGL(k_zone_scatter<0>, sgrid, sblock, lds_bins, stream, w.dest, ids, n, Z, chunk, cur, w.base,
+                               ids_next, off_next);
             ids = ids_next;
             off = off_next;
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zone hour launch");
+    }
+    if (ivp) {
+        // the final buckets describe the new state: keep them as the cached initial bucketing and
+        // write the state back car-indexed (initial_state of src/solveinitialvalueproblem.jl:57-58)
+        if (ids != w.ids0) {
+            if ((e = hipMemcpyAsync(w.ids0, ids, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                return hip_fail(e, "copy buckets");
+            if ((e = hipMemcpyAsync(w.off0, off, sizeof(uint32_t) * (Z + 1), hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                return hip_fail(e, "copy offsets");
+        }
+        hipLaunchKernelGGL(k_zone_unbucket, dim3(Z), dim3(256), 0, stream, w.ids0, w.off0, d_zone0_out);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
+        w.buckets0_valid = true;
     }
     return CPM_OK;
 }
@@ -427,6 +447,7 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
                                uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
                                const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row)
 {
+#ifdef CPM_DIAGNOSTIC
     if (w.ablate & 7) {  // diagnostic ablations, 256-thread form only
         switch (w.ablate & 7) {
         case 1: CPM_ZS_CALL(256, 1); break;
@@ -437,6 +458,7 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
         }
         return;
     }
+#endif
     switch (w.block) {
     case 128: CPM_ZS_CALL(128, 0); break;
     case 512: CPM_ZS_CALL(512, 0); break;

@@ -150,6 +150,8 @@ int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
  * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
  * stream); returns the number written through *n_out */
 int32_t cpm_last_kernel_ms(cpm_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
+/* diagnostic (CPM_OPT_ABLATE 4): cycle sums of the fused sampler's segments since the last call */
+int32_t cpm_debug_cycles(cpm_ctx *ctx, uint64_t *out8);
 /* algorithmic HBM bytes of one hourly sampler launch */
 int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *ctx, int64_t *bytes_out);
 

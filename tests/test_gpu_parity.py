@@ -7,7 +7,8 @@ from conftest import SIM_SEED, TABLE_SEED
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [pytest.param(1, id="car"), pytest.param(2, id="zone_lds"), pytest.param(3, id="zone_fused")]
+KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
+           pytest.param(3, id="zone_fused")]
 
 
 def _tables(O, Z, T=24, seed=TABLE_SEED):
@@ -283,3 +284,66 @@ def test_reference_call_surface_main_jl(cpm, O, tmp_path):
     finally:
         cpm.release()
         cpm.params.__init__()
+
+
+def test_headline_config_full_size(cpm, O):
+    """BASELINE.json configs[2] at full size (Z = 4,096, 1,000 cars/zone, C = 4,096,000): tables built
+    on the device by cpm_synth_tables, IVP + resample on the device, against the oracle's fast twin
+    on oracle-built tables -- post-IVP state and both count tensors bit-exact -- plus the
+    size-independent properties (every hour holds all C cars; repeatable; shards add up)."""
+    from carparkingmaps_amd.distributed import shard_range
+    Z, T, cpz = 4096, 24, 1000
+    C = Z * cpz
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)
+    cdf = O.build_cdf(p_dest)
+    del p_dest
+    ref = O.fast_run(p_drive, cdf, C, SIM_SEED, _zone0(C, cpz))
+    del cdf
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED)
+        assert np.array_equal(s.get_p_drive(), p_drive)
+        s.init_states(C, cpz)
+        init = s.solve_ivp(SIM_SEED)
+        assert np.array_equal(init, ref["zone0"])
+        r = s.resample(SIM_SEED)
+        assert np.array_equal(r["parking"], ref["parking"])
+        assert np.array_equal(r["driving"], ref["driving"])
+        assert (r["parking"].sum(axis=0) == C).all()
+        np.testing.assert_allclose(r["parking"] / C, ref["parking"] / C, rtol=1e-6, atol=0)
+        for kernel in (1, 3):  # the other kernels agree at full size too
+            s.set_kernel(kernel)
+            r2 = s.resample(SIM_SEED)
+            assert np.array_equal(r2["parking"], ref["parking"]) and np.array_equal(r2["driving"], ref["driving"])
+        s.set_kernel(0)
+        # two shards of the same fleet add up to the whole (Philox keyed by the global car id)
+        pk = np.zeros((Z, T), dtype=np.int64)
+        for rank in range(2):
+            b, n = shard_range(C, rank, 2)
+            s.init_states(C, cpz, b, n)
+            s.set_state(init[b:b + n])
+            pk += s.resample(SIM_SEED)["parking"]
+        assert np.array_equal(pk, ref["parking"])
+
+
+def test_melbourne_shaped_config(cpm, O):
+    """BASELINE.json configs[1] shape (Z = 2,357 zones; here 200 cars/zone to keep the oracle quick):
+    sparse Melbourne-shaped datamatrix -> createpdrive / createpdestin on the device -> IVP ->
+    resample with travel times, against the oracle run on the tables the device returned."""
+    Z, T, cpz = 2357, 24, 200
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED)
+    with cpm.Sampler(Z, T) as s:
+        s.set_datamatrix(dm, dist)
+        p_drive = s.build_p_drive(0.1, 0.9, 0.5)
+        p_dest = s.build_p_dest(2)
+        want_pd = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5)
+        np.testing.assert_allclose(p_drive, want_pd, rtol=4e-16, atol=0, equal_nan=True)
+        assert np.array_equal(p_dest, O.createpdestin(dm, Z, T, 2))
+        ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED, travel=True)
+    assert np.array_equal(r["parking"], ref["parking"])
+    assert np.array_equal(r["driving"], ref["driving"])
+    assert r["sum_tt_q16"] == ref["sum_tt_q16"]

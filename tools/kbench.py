@@ -50,4 +50,11 @@ for cfg in args.configs.split(","):
         if ref is None:
             ref = r
         ok = "counts==first" if np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]) else "COUNTS DIFFER"
+    if int(abl) & 4:
+        buf = (ctypes.c_uint64 * 8)()
+        _lib.check(L.cpm_debug_cycles(s._h, ctypes.cast(buf, ctypes.c_void_p)))
+        tot = sum(buf) or 1
+        names = ["loop-top", "row wait + tree write", "prefetch issue + barrier", "philox + search", "compact + stores",
+                 "extra rounds + reductions", "closing barrier", "ticket"]
+        print("   segment shares:", ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, buf)))
     print(f"{cfg:16s} resample {dt*1e3:8.3f} ms   sampler launch avg {np.mean(ms)*1e3:8.1f} us (min {np.min(ms)*1e3:.1f} max {np.max(ms)*1e3:.1f}, n={len(ms)})  {C*T/dt:.3e} car-steps/s {ok}", flush=True)
