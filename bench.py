@@ -65,6 +65,22 @@ def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
             "counts_match_gpu": ok}
 
 
+def pmc_traffic(kernel, Z, cars_per_gpu):
+    """HBM bytes per sampler launch from the committed PMC run of this same command
+    (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in their own rocprofv3 passes, corrected as
+    MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  None when no run matches."""
+    if Z != 4096 or cars_per_gpu != 4096000:
+        return None, None
+    name = {0: "k_zone_sample", 2: "k_zone_sample", 1: "k_step_car", 3: "k_zone2_sample"}[kernel]
+    for f in ("round1_bench_zone_lds_traffic.json",):
+        path = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(path):
+            for k, v in json.load(open(path)).items():
+                if name in k and v.get("launches", 0) > 0:
+                    return v["hbm_bytes_per_launch"], "profiles/" + f
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +150,7 @@ def main():
         alg_bytes = s.algorithmic_bytes_per_hour()
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(args.kernel, Z, count)
         out = {
             "metric": "car-steps/sec at Z=4,096, 1k cars/zone; 1/2/4/8 MI355X + %HBM roofline",
             "value": car_steps * args.steps / dt,
@@ -155,7 +172,7 @@ def main():
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
                        "device": cpm.device_info(local_rank)["name"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "hourly sampler launch", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms)},
         }

@@ -371,8 +371,10 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->n_prof = 0;  // (re)start the record; hourly launches append until read or reset
         return CPM_OK;
     case CPM_OPT_ZONE_BLOCK:
-        if (value != 128 && value != 256 && value != 512 && value != 1024) return fail(CPM_ERR_ARG, "zone block %lld", (long long)value);
-        c->zw.block = static_cast<int>(value);
+        // 0: the default tree-layout sampler; 256 / 512: the first-generation sorted-row sampler of that size
+        if (value != 0 && value != 256 && value != 512) return fail(CPM_ERR_ARG, "zone block %lld", (long long)value);
+        c->zw.tree = (value == 0);
+        if (value) c->zw.block = static_cast<int>(value);
         c->zw2.block = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_ZONE_CPT:

@@ -159,6 +159,40 @@ __device__ __forceinline__ int lower_bound_row(RowT row, int n, double ue)
     return lo;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// A CDF row as an implicit binary search tree in breadth-first (Eytzinger) order, the LDS
+// layout of the zone kernels: the sorted layout's probes sit at power-of-two strides, which all
+// map to the same LDS banks (72 % of the LDS cycles of the first zone kernel were bank
+// conflicts); breadth-first, the top levels are broadcast reads and the rest spread evenly.
+// Tree over elements 0..Z-2 (height H, 2^H >= Z); slot 0 holds element Z-1 (the row total);
+// slots of ranks Z..2^H-1 hold +inf.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int tree_height(int Z)
+{
+    int h = 1;
+    while ((1 << h) < Z) ++h;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t eytz_pos(uint32_t e, int Z, int H)
+{
+    if (e == static_cast<uint32_t>(Z - 1)) return 0u;
+    uint32_t r = e + 1;
+    int tz = __builtin_ctz(r);
+    return (1u << (H - 1 - tz)) + (r >> (tz + 1));
+}
+
+// tree walk result -> sorted index of the first element >= ue (ue <= last guarantees one exists)
+__device__ __forceinline__ uint32_t eytz_decode(uint32_t i, int Z, int H)
+{
+    i >>= __ffs(static_cast<int>(~i));
+    if (i == 0) return static_cast<uint32_t>(Z - 1);
+    int lv = 31 - __clz(static_cast<int>(i));
+    uint32_t off = i - (1u << lv);
+    return ((2 * off + 1) << (H - 1 - lv)) - 1;
+}
+
 // travel time of one driving car-hour (src/resampling.jl:57-69), q16 fixed point
 __device__ __forceinline__ long long travel_time_q16(const double *__restrict__ dm, int Z, int T, int t,
                                                      uint32_t origin, uint32_t dest, uint64_t seed,

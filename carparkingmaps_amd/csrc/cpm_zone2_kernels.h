@@ -75,26 +75,6 @@ struct Zone2Args {
     uint64_t seed;
 };
 
-__device__ __forceinline__ uint32_t eytz_pos(uint32_t e, int Z, int H)
-{
-    // element e (0-based, sorted order) -> slot of the breadth-first tree over elements 0..Z-2;
-    // slot 0 holds element Z-1 (= the row total, "last")
-    if (e == static_cast<uint32_t>(Z - 1)) return 0u;
-    uint32_t r = e + 1;
-    int tz = __builtin_ctz(r);
-    return (1u << (H - 1 - tz)) + (r >> (tz + 1));
-}
-
-// tree walk result -> sorted index of the first element >= ue (ue <= last guarantees one exists)
-__device__ __forceinline__ uint32_t eytz_decode(uint32_t i, int Z, int H)
-{
-    i >>= __ffs(static_cast<int>(~i));
-    if (i == 0) return static_cast<uint32_t>(Z - 1);
-    int lv = 31 - __clz(static_cast<int>(i));
-    uint32_t off = i - (1u << lv);
-    return ((2 * off + 1) << (H - 1 - lv)) - 1;
-}
-
 // NP: 16-B row pieces per thread (>= Zp / 2 / BLOCK).  CPT: cars per thread in the straight-line
 // part.  LAST: final hour (no next-hour state).  ABL (diagnostic, results wrong but every index
 // stays in range): 1 = no tree search, 2 = cheap hash instead of Philox.
@@ -576,12 +556,7 @@ struct Zone2Work {
     }
 };
 
-inline int zone2_tree_height(int Z)
-{
-    int h = 1;
-    while ((1 << h) < Z) ++h;
-    return h;
-}
+inline int zone2_tree_height(int Z) { return tree_height(Z); }
 
 inline size_t zone2_sample_lds(int Z) { return sizeof(double) * (size_t(1) << zone2_tree_height(Z)) + sizeof(uint32_t) * Z; }
 inline bool zone2_path_fits(int Z)

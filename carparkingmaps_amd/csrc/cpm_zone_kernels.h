@@ -95,6 +95,133 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample(
     }
 }
 
+// Second form of the zone sampler (the default): same contract as k_zone_sample, plus
+//   * the car ids of the bucket are requested BEFORE the row (vmcnt retires in order: by the time
+//     the row has landed and the barrier has passed they are there, instead of one exposed HBM
+//     round trip per round of cars);
+//   * the row is written into LDS as a breadth-first search tree (see cpm_kernels.h);
+//   * every thread carries CPT cars through straight-line code: independent Philox chains and
+//     tree walks interleave (CPT LDS reads in flight per lane);
+//   * Bernoulli draw in integers (k <= floor(p * 2^53)).
+// NP: 16-B row pieces per thread (>= Zp / 2 / BLOCK).
+template <bool TRAVEL, int BLOCK, int NP, int CPT>
+__global__ __launch_bounds__(BLOCK) void k_zone_sample2(
+    const uint32_t *__restrict__ ids, const uint32_t *__restrict__ off, uint32_t *__restrict__ dest_out,
+    const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int H, int64_t car_begin,
+    uint32_t step, uint64_t seed, unsigned long long *__restrict__ parking_t,
+    unsigned long long *__restrict__ driving_t, const double *__restrict__ dm, int T, int t,
+    unsigned long long *tt_sum)
+{
+    extern __shared__ double row[];  // 2^H doubles: the zone's CDF row as a search tree
+    __shared__ uint32_t s_ndrive;
+    __shared__ unsigned long long s_tt;
+    const int z = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t b = off[z], e = off[z + 1], n = e - b;
+    if (tid == 0) {
+        parking_t[z] = n;  // every car present at hour t, drivers included (Appendix A-14)
+        s_ndrive = 0;
+        s_tt = 0;
+    }
+    if (n == 0) return;  // driving_t[z] stays 0 (zeroed by the caller)
+    uint32_t id[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) id[c] = ids[b + min(static_cast<uint32_t>(tid + c * BLOCK), n - 1)];
+    double2 pc[NP];
+    const double2 *src = reinterpret_cast<const double2 *>(cdf_t + static_cast<size_t>(z) * Zp);
+#pragma unroll
+    for (int m = 0; m < NP; ++m) pc[m] = src[min(tid + m * BLOCK, Zp / 2 - 1)];
+    const long long thr = bernoulli_threshold(pdrive_t[z]);
+    const int P = 1 << H;
+    for (int r = Z + tid; r < P; r += BLOCK) {  // ranks Z..2^H-1: +inf
+        int tz = __builtin_ctz(static_cast<unsigned>(r));
+        row[(1u << (H - 1 - tz)) + (static_cast<unsigned>(r) >> (tz + 1))] = __builtin_huge_val();
+    }
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        int j = tid + m * BLOCK;
+        if (2 * j < Zp) {
+            uint32_t el = 2 * j;
+            if (el < static_cast<uint32_t>(Z)) row[eytz_pos(el, Z, H)] = pc[m].x;
+            if (el + 1 < static_cast<uint32_t>(Z)) row[eytz_pos(el + 1, Z, H)] = pc[m].y;
+        }
+    }
+    __syncthreads();
+    const double last = row[0];
+    uint32_t nd = 0;
+    long long tt = 0;
+    {  // CPT cars per thread, straight line
+        bool valid[CPT], drive[CPT], any_search = false;
+        uint32_t dest[CPT];
+        double ue[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
+            long long kb;
+            double uc;
+            car_draws(seed, static_cast<uint64_t>(car_begin) + id[c], step, kb, uc);
+            drive[c] = valid[c] && (kb <= thr);
+            dest[c] = z;
+            ue[c] = clamp_u(uc, last);
+            any_search |= drive[c] && last != 0.0;
+        }
+        if (__any(any_search)) {
+            uint32_t i[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) i[c] = 1;
+            for (int l = 0; l < H; ++l) {
+                double k[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) k[c] = row[i[c]];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) i[c] = 2 * i[c] + (k[c] < ue[c] ? 1u : 0u);
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (drive[c] && last != 0.0) dest[c] = eytz_decode(i[c], Z, H);
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (valid[c]) dest_out[b + tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
+            if (drive[c]) {
+                ++nd;
+                if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest[c], seed, static_cast<uint64_t>(car_begin) + id[c], step);
+            }
+        }
+    }
+    for (uint32_t s = b + CPT * BLOCK + tid; s < e; s += BLOCK) {  // buckets larger than CPT*BLOCK cars
+        const uint32_t idx = ids[s];
+        const uint64_t car = static_cast<uint64_t>(car_begin) + idx;
+        long long kb;
+        double uc;
+        car_draws(seed, car, step, kb, uc);
+        const bool drive = kb <= thr;
+        uint32_t dest = z;
+        if (drive) {
+            if (last != 0.0) {
+                const double u1 = clamp_u(uc, last);
+                uint32_t i = 1;
+                for (int l = 0; l < H; ++l) i = 2 * i + (row[i] < u1 ? 1u : 0u);
+                dest = eytz_decode(i, Z, H);
+            }
+            if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest, seed, car, step);
+            ++nd;
+        }
+        dest_out[s] = dest | (drive ? kDriveBit : 0u);
+    }
+    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+    if ((tid & 63) == 0 && nd) atomicAdd(&s_ndrive, nd);
+    if (TRAVEL) {
+        for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
+        if ((tid & 63) == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        driving_t[z] = s_ndrive;
+        if (TRAVEL && s_tt) atomicAdd(tt_sum, s_tt);
+    }
+}
+
 // Wave-aggregated LDS atomics.  The slots of a chunk are ordered by origin zone and about half
 // the cars stay where they are, so within one wave-instruction dozens of lanes carry the SAME
 // key (their own zone, drive flag clear): plain LDS atomics on one address serialise (measured:
@@ -279,6 +406,7 @@ struct ZoneWork {
     bool buckets0_valid = false;  // ids0/off0 describe the context's current car state
     int block = 512;              // workgroup size of k_zone_sample (tuning knob; 512 measured best at Z = 4096)
     int ablate = 0;               // diagnostic: see k_zone_sample ABL
+    bool tree = true;             // k_zone_sample2 (tree layout) instead of k_zone_sample (sorted row)
     int64_t n = 0;
     int Z = 0, T = 0, nb = 0;
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [n]
@@ -327,7 +455,10 @@ struct ZoneWork;
 inline size_t zone_sample_lds(int Zp) { return sizeof(double) * static_cast<size_t>(Zp); }
 
 // true when the zone path can run this problem (LDS row + sort bins must fit a CU's 160 KiB)
-inline bool zone_path_fits(int Zp) { return zone_sample_lds(Zp) + 64 <= 160 * 1024; }
+inline bool zone_path_fits(int Zp)
+{
+    return sizeof(double) * (size_t(1) << tree_height(Zp)) + 64 <= 160 * 1024 && zone_sample_lds(Zp) + 64 <= 160 * 1024;
+}
 
 #define CPM_ZS_ARGS ids, off, w.dest, pd, cdf, Z, Zp, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum
 
@@ -371,10 +502,8 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
     const size_t lds_row = zone_sample_lds(Zp), lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
     if (w.tables_dirty) {  // LDS opt-in above 64 KiB, once per context / table size
         if (lds_row > 64 * 1024) {
-            const void *fns[] = {reinterpret_cast<const void *>(k_zone_sample<false, 128, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 128, 0>),
-                                 reinterpret_cast<const void *>(k_zone_sample<false, 256, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 256, 0>),
-                                 reinterpret_cast<const void *>(k_zone_sample<false, 512, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 512, 0>),
-                                 reinterpret_cast<const void *>(k_zone_sample<false, 1024, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 1024, 0>)};
+            const void *fns[] = {reinterpret_cast<const void *>(k_zone_sample<false, 256, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 256, 0>),
+                                 reinterpret_cast<const void *>(k_zone_sample<false, 512, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 512, 0>)};
             for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_row));
         }
         if (lds_bins > 64 * 1024) {
@@ -459,10 +588,36 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
         return;
     }
 #endif
+    if (w.tree) {  // default: tree layout, id prefetch, three cars per thread
+        const int H = tree_height(Z);
+        const size_t lds_tree = sizeof(double) * (size_t(1) << H);
+        const int need = (Zp / 2 + 511) / 512;
+#define CPM_ZS2(NPV)                                                                                                     \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done && lds_tree > 64 * 1024) {                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<false, 512, NPV, 3>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<true, 512, NPV, 3>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        if (travel)                                                                                                      \
+            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, w.dest, pd, \
+                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum);           \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, w.dest, pd, \
+                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum);           \
+    } while (0)
+        if (need <= 1) CPM_ZS2(1);
+        else if (need <= 2) CPM_ZS2(2);
+        else if (need <= 4) CPM_ZS2(4);
+        else if (need <= 8) CPM_ZS2(8);
+        else CPM_ZS2(16);
+        return;
+    }
     switch (w.block) {
-    case 128: CPM_ZS_CALL(128, 0); break;
     case 512: CPM_ZS_CALL(512, 0); break;
-    case 1024: CPM_ZS_CALL(1024, 0); break;
     default: CPM_ZS_CALL(256, 0); break;
     }
 }

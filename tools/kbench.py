@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=4096)
 ap.add_argument("--cpz", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--configs", default="car:256:0,zone:256:0,zone:512:0,zone:1024:0,zone:256:1,zone:256:2,zone:256:4,zone:256:7")
+ap.add_argument("--configs", default="car:0:0,zone:512:0,zone:0:0,fused:0:0")
 args = ap.parse_args()
 
 Z, T, cpz = args.zones, 24, args.cpz
