@@ -299,10 +299,24 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_hist(const uint32_t *__rest
     }
     for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += kSortBlock) atomicAdd(&bins[key[i] & kZoneMask], 1u);
     __syncthreads();
+    // ticket: this block's range inside every bucket.  Four returning atomics per thread are issued
+    // back to back (index clamped, count 0 out of range: straight-line code) and waited for once,
+    // instead of four dependent HBM-side round trips.
     uint32_t *mybase = base + static_cast<size_t>(blockIdx.x) * Z;
-    for (int z = threadIdx.x; z < Z; z += kSortBlock) {
-        uint32_t c = bins[z];
-        mybase[z] = c ? atomicAdd(&cursor[z], c) : 0u;  // this block's range inside bucket z
+    for (int zb = 0; zb < Z; zb += kSortBlock * 4) {
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + threadIdx.x + k * kSortBlock;
+            const int zc = min(z, Z - 1);
+            const uint32_t c = (z < Z) ? bins[zc] : 0u;
+            r[k] = atomicAdd(&cursor[zc], c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + threadIdx.x + k * kSortBlock;
+            if (z < Z) mybase[z] = r[k];
+        }
     }
 }
 
@@ -318,29 +332,46 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_scatter(const uint32_t *__r
     extern __shared__ uint32_t pos[];  // Z
     __shared__ uint32_t wsum[kSortBlock / 64];
     const int tid = threadIdx.x;
-    // exclusive scan of the Z bucket sizes, redone by every block (reads Z*4 B from L2)
-    const int per = (Z + kSortBlock - 1) / kSortBlock;
-    const int z0 = tid * per;
-    uint32_t mine = 0;
-    for (int k = 0; k < per; ++k)
-        if (z0 + k < Z) mine += cursor[z0 + k];
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += v;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
-    uint32_t run = wbase + incl - mine;
+    // exclusive scan of the Z bucket sizes, redone by every block (Z*4 B from L2): thread t takes
+    // zones t, t+1024, ... so that its loads of cursor[] and base[] are coalesced and all issued
+    // before the first use; one block scan per 1024-zone chunk, carry in a register.
     const uint32_t *mybase = base + static_cast<size_t>(blockIdx.x) * Z;
-    for (int k = 0; k < per; ++k) {
-        int z = z0 + k;
-        if (z < Z) {
-            pos[z] = run + mybase[z];
-            if (blockIdx.x == 0) off_next[z] = run;
-            run += cursor[z];
+    uint32_t carry = 0;
+    for (int zb = 0; zb < Z; zb += kSortBlock * 4) {
+        uint32_t cnt[4], bs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + tid + k * kSortBlock;
+            const int zc = min(z, Z - 1);
+            cnt[k] = cursor[zc];
+            bs[k] = mybase[zc];
+            if (z >= Z) cnt[k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + tid + k * kSortBlock;
+            uint32_t incl = cnt[k];
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = __shfl_up(incl, o, 64);
+                if ((tid & 63) >= o) incl += v;
+            }
+            __syncthreads();  // wsum free
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < kSortBlock / 64; ++w) {
+                const uint32_t sw = wsum[w];
+                if (w < (tid >> 6)) wbase += sw;
+                tot += sw;
+            }
+            const uint32_t excl = carry + wbase + incl - cnt[k];
+            if (z < Z) {
+                pos[z] = excl + bs[k];
+                if (blockIdx.x == 0) off_next[z] = excl;
+            }
+            carry += tot;
+            if (zb + (k + 1) * kSortBlock >= Z) break;
         }
     }
     if (blockIdx.x == 0 && tid == 0) off_next[Z] = static_cast<uint32_t>(n);
