@@ -1,0 +1,190 @@
+"""Model selection on top of the sampler path (BASELINE.json configs[4]).
+
+The reference tunes its four hyper-parameters with three sequential 1-D searches that live only
+in the notebook (README.md:947-2435 of the reference): e_drive against the measured circadian
+traffic activity (README.md:1134-1314), (p_min, p_max) against the share of life spent driving
+A_set = 0.07 (README.md:1436-1676, clamp = src/correctparameters.jl:3-22) and e_dest against the
+measured parking densities (README.md:2062-2276).  Every iteration = rebuild one table -> reset
+state_matrix[:,1] = initial_state (the IVP is NOT re-run: README.md:1180,1549,2119) -> 24-hour
+resample -> histogram -> scalar error.  Here one iteration is one `evaluate()` on the device:
+cpm_build_p_drive / cpm_build_p_dest + cpm_resample from the cached post-IVP state.
+
+`grid_sweep` is the build's generalisation named by BASELINE.json: a grid of
+(e_drive, p_min, p_max, e_dest) points, dealt round-robin over the ranks of a torch.distributed
+job (one process per GPU).  Points are independent, so there is NO collective on the data path;
+the per-point scalars are gathered at the end.  Points sharing e_dest share the CDF (the
+3 GB table is rebuilt only when e_dest changes), so each rank sorts its points by e_dest.
+
+The reference's measured validation data (traffic_activity_measured.jld2, parking_density_measured.jld2)
+are not in the repository; callers pass their own vectors (tests use synthetic ones).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .reference_api import correctparameters
+
+
+# ------------------------------------------------------------------ objectives (host scalars)
+def traffic_activity(driving):
+    """min-max normalised column sums of the driving counts (src/saveresults.jl:23-28)."""
+    a = np.asarray(driving, dtype=np.float64).sum(axis=0)
+    with np.errstate(all="ignore"):
+        return (a - a.min()) / (a.max() - a.min())
+
+
+def traffic_activity_error(activity, measured):
+    """mean squared error over the 24 hours (README.md:1279-1283)."""
+    d = np.asarray(measured, dtype=np.float64) - np.asarray(activity, dtype=np.float64)
+    return float(np.sum(d * d) / d.size)
+
+
+def a_drive(sum_tt_q16, C, T=24):
+    """share of life spent driving (src/averagedrivingtime.jl:10) from the fixed-point time sum."""
+    return (sum_tt_q16 / 65536.0) / (C * T * 60 * 60)
+
+
+def parking_density_error(parking, C, measured):
+    """README.md:2219-2244: per-zone min-max normalisation over the day (zones with max == min are
+    left as they are), MSE over 24 h for zones that are measured (row sum != 0) and not flat, averaged
+    over the validated zones."""
+    p = np.asarray(parking, dtype=np.float64) / C
+    m = np.asarray(measured, dtype=np.float64)
+    lo, hi = p.min(axis=1, keepdims=True), p.max(axis=1, keepdims=True)
+    flat = (hi == lo)[:, 0]
+    with np.errstate(all="ignore"):
+        pn = np.where(flat[:, None], p, (p - lo) / (hi - lo))
+    valid = (m.sum(axis=1) != 0) & ~flat
+    if not valid.any():
+        return float("nan")
+    err = ((pn[valid] - m[valid]) ** 2).sum(axis=1) / p.shape[1]
+    return float(err.sum() / valid.sum())
+
+
+# ------------------------------------------------------------------ one evaluation
+@dataclass
+class Point:
+    e_drive: float = 0.5
+    p_min: float = 0.1
+    p_max: float = 0.9
+    e_dest: object = 2
+
+
+@dataclass
+class Evaluator:
+    """Holds a Sampler whose datamatrix is uploaded and whose car state is the post-IVP state."""
+    sampler: object
+    C: int
+    seed: int
+    measured_activity: object = None
+    measured_parking: object = None
+    travel: bool = True
+    _e_dest: object = field(default=None, repr=False)
+
+    def evaluate(self, pt):
+        s = self.sampler
+        s.build_p_drive(pt.p_min, pt.p_max, pt.e_drive, want=False)
+        key = (type(pt.e_dest).__name__, float(pt.e_dest))
+        if key != self._e_dest:              # the CDF is rebuilt only when e_dest changes
+            s.build_p_dest(pt.e_dest, want=False)
+            self._e_dest = key
+        r = s.resample(self.seed, travel=self.travel)
+        act = traffic_activity(r["driving"])
+        out = {"e_drive": pt.e_drive, "p_min": pt.p_min, "p_max": pt.p_max, "e_dest": float(pt.e_dest),
+               "A_drive": a_drive(r["sum_tt_q16"], self.C, s.T), "traffic_activity": act,
+               "parking": r["parking"], "driving": r["driving"]}
+        if self.measured_activity is not None:
+            out["activity_error"] = traffic_activity_error(act, self.measured_activity)
+        if self.measured_parking is not None:
+            out["parking_error"] = parking_density_error(r["parking"], self.C, self.measured_parking)
+        return out
+
+
+# ------------------------------------------------------------------ the reference's three searches
+def search_exponent(evaluate_error, initial_values, step_size=10.0, max_iter=3, epsilon=0.001, good=0.02):
+    """README.md:1100-1314 (e_drive) and 2040-2276 (e_dest): pick the best of a few initial values,
+    take one step, then secant-like updates e <- e - step * d(error)/d(e), resetting to the best
+    value whenever the error got worse.  Returns (best_value, best_error, history)."""
+    hist = [(v, evaluate_error(v)) for v in initial_values]
+    best, best_err = min(hist, key=lambda x: x[1])
+    e = best + step_size * best_err                                        # Step 3.1
+    for _ in range(max_iter):
+        err = evaluate_error(e)
+        hist.append((e, err))
+        error_gradient = err - best_err
+        param_gradient = e - best
+        if error_gradient < 0:
+            best_err, best = err, e
+        else:
+            e = best
+        if param_gradient == 0:
+            break
+        e = e - step_size * error_gradient / param_gradient                # Step 3.2.6
+        if best_err < good or abs(error_gradient) < epsilon:
+            break
+    return best, best_err, hist
+
+
+def tune_p_min_max(evaluate_a_drive, A_set=0.07, p_min=0.1, p_max=0.9, max_iter=5):
+    """README.md:1436-1676: move p_max (or p_min at the bounds) until A_drive matches A_set to the
+    percent; clamp with correctparameters; reset when |dA| grows."""
+    pm, px = [p_min], [p_max]
+    A = [evaluate_a_drive(p_min, p_max)]
+    dA = [A_set - A[0]]
+    for n in range(2, max_iter + 1):
+        a, b, d, ad = pm[-1], px[-1], dA[-1], A[-1]
+        step = (b + a) * d / (n * ad)
+        if b == 1:
+            if a == b:
+                break
+            na, nb = a + step, b
+        elif a == 0:
+            if a == b:
+                break
+            na, nb = a, b + step
+        elif a == b:
+            na, nb = a + step, b
+        else:
+            na, nb = a, b + step
+        na, nb = correctparameters(na, nb, a, b)
+        an = evaluate_a_drive(na, nb)
+        dn = A_set - an
+        if int(A_set * 100) == int(an * 100):
+            pm.append(na); px.append(nb); A.append(an); dA.append(dn)
+            break
+        if n > 2 and abs(dn) > abs(d):                                      # worse: reset
+            na, nb, an, dn = a, b, ad, A_set - ad
+        pm.append(na); px.append(nb); A.append(an); dA.append(dn)
+    return pm[-1], px[-1], A[-1], list(zip(pm, px, A))
+
+
+# ------------------------------------------------------------------ the grid of config 5
+def make_grid(e_drive=(0.25, 0.5, 1.0, 2.0), p_min=(0.0, 0.05, 0.1, 0.2), p_max=(0.5, 0.7, 0.9, 1.0),
+              e_dest=(0.5, 1, 2, 4)):
+    """4 x 4 x 4 x 4 = 256 points by default."""
+    return [Point(a, b, c, d) for d in e_dest for a in e_drive for b in p_min for c in p_max]
+
+
+def points_of_rank(n_points, rank, world_size):
+    """Round-robin deal: independent points, no data-path collective."""
+    return list(range(rank, n_points, world_size))
+
+
+def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True):
+    """Evaluate this rank's share of `grid`; returns a list (on every rank when gather) of dicts with the
+    per-point scalars, ordered like `grid`."""
+    mine = points_of_rank(len(grid), rank, world_size)
+    mine.sort(key=lambda i: (type(grid[i].e_dest).__name__, float(grid[i].e_dest)))   # share the CDF
+    local = {}
+    for i in mine:
+        r = evaluator.evaluate(grid[i])
+        local[i] = {k: v for k, v in r.items() if np.isscalar(v)}
+        local[i]["driving_total"] = int(r["driving"].sum())
+    if world_size > 1 and gather:
+        import torch.distributed as dist
+        parts = [None] * world_size
+        dist.all_gather_object(parts, local)
+        local = {}
+        for p in parts:
+            local.update(p)
+    return [local.get(i) for i in range(len(grid))]
