@@ -105,10 +105,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # CPM_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (every
+    # rank on the visible devices round-robin, gloo instead of RCCL).  Never used for reported numbers.
+    rehearse = os.environ.get("CPM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     Z, T = args.zones, 24
     cpz = args.cars_per_zone * world
@@ -126,6 +134,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rehearse and world > 1:  # gloo cannot reduce device tensors: bounce through the host
+        def resample_allreduce(seed):
+            with torch.cuda.stream(ss.stream):
+                s.resample_dev(seed, ss.counts.data_ptr())
+                host = ss.counts.cpu()
+                dist.all_reduce(host)
+                ss.counts.copy_(host)
+            return ss.counts
+        ss.resample_allreduce = resample_allreduce
+
     for _ in range(args.warmup):
         ss.resample_allreduce(SIM_SEED)
     barrier()
@@ -137,7 +155,7 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = s.last_kernel_ms()
     s.set_profile(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -163,7 +181,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: gloo, shared GPU -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,

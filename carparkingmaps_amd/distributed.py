@@ -50,8 +50,12 @@ class ShardedSampler:
         self.s = Sampler(number_zones, T, self.device)
         self.Z, self.T = int(number_zones), int(T)
         self.counts = torch.zeros(self.s.counts_words(), dtype=torch.int64, device=f"cuda:{self.device}")
-        # run on torch's current stream so that the all-reduce is ordered behind the kernels
-        self.s.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # One explicit torch stream carries both the kernels and the collective, so the all-reduce is
+        # ordered behind the resample without a host synchronisation.  (torch's default stream has
+        # handle 0, which the C ABI reads as "use the context's own stream" -- never rely on it.)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.s.set_stream(self.stream.cuda_stream)
+        torch.cuda.synchronize(self.device)  # counts zero-filled before the first enqueue on self.stream
 
     def init_states(self, C_total, cars_per_zone):
         begin, count = shard_range(C_total, self.rank, self.world_size)
@@ -61,9 +65,13 @@ class ShardedSampler:
 
     def resample_allreduce(self, seed, travel=False):
         """Enqueue the fused resample of this shard and the all-reduce; returns the device tensor."""
-        self.s.resample_dev(seed, self.counts.data_ptr(), travel=travel)
-        allreduce_counts(self.counts)
+        with torch.cuda.stream(self.stream):
+            self.s.resample_dev(seed, self.counts.data_ptr(), travel=travel)
+            allreduce_counts(self.counts)
         return self.counts
+
+    def synchronize(self):
+        self.stream.synchronize()
 
     def close(self):
         self.s.close()

@@ -347,3 +347,30 @@ def test_melbourne_shaped_config(cpm, O):
     assert np.array_equal(r["parking"], ref["parking"])
     assert np.array_equal(r["driving"], ref["driving"])
     assert r["sum_tt_q16"] == ref["sum_tt_q16"]
+
+
+def test_sharded_sampler_stream_ordering(cpm, O):
+    """ShardedSampler runs the kernels and the collective on one explicit torch stream: reading the
+    count tensor on that stream, with no host synchronisation in between, must see the finished
+    resample (a rehearsal caught the all-reduce racing the kernels when torch's default stream,
+    handle 0, was handed to the C ABI)."""
+    import torch
+    from carparkingmaps_amd.distributed import ShardedSampler, split_counts
+    Z, T, cpz = 512, 24, 300
+    C = Z * cpz
+    p_drive, p_dest = _tables(O, Z, T)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    ss = ShardedSampler(Z, T, rank=0, world_size=1, device=0)
+    try:
+        ss.s.set_p_drive(p_drive)
+        ss.s.set_p_dest(p_dest)
+        ss.init_states(C, cpz)
+        ss.s.solve_ivp_async(SIM_SEED)
+        for _ in range(3):
+            counts = ss.resample_allreduce(SIM_SEED)
+            with torch.cuda.stream(ss.stream):
+                host = counts.to("cpu", non_blocking=False)
+            pk, dr, _ = split_counts(host, Z, T)
+            assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
+    finally:
+        ss.close()
