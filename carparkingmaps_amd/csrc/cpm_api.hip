@@ -83,6 +83,9 @@ struct cpm_ctx {
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
+    int prof_stride = 1;      // bracket every prof_stride-th hourly sampler launch
+    int64_t prof_seen = 0;    // sampler launches since profiling was switched on
+    bool prof_open = false;
     std::vector<hipEvent_t> ev;  // 2 per hourly launch
     int n_prof = 0;
 };
@@ -157,7 +160,10 @@ constexpr int kMaxProf = 8192;
 
 void prof_begin(cpm_ctx *c)
 {
+    c->prof_open = false;
     if (!c->profile || c->n_prof >= kMaxProf) return;
+    if ((c->prof_seen++ % c->prof_stride) != 0) return;  // an event pair costs ~2 x 5 us of stream bubbles: sample
+    c->prof_open = true;
     size_t k = static_cast<size_t>(c->n_prof) * 2;
     while (c->ev.size() < k + 2) {
         hipEvent_t e;
@@ -169,7 +175,8 @@ void prof_begin(cpm_ctx *c)
 
 void prof_end(cpm_ctx *c)
 {
-    if (!c->profile || c->n_prof >= kMaxProf) return;
+    if (!c->prof_open) return;
+    c->prof_open = false;
     size_t k = static_cast<size_t>(c->n_prof) * 2;
     if (c->ev.size() < k + 2) return;
     (void)hipEventRecord(c->ev[k + 1], c->stream);
@@ -368,6 +375,8 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         return CPM_OK;
     case CPM_OPT_PROFILE:
         c->profile = value != 0;
+        c->prof_stride = value > 1 ? static_cast<int>(value) : 1;
+        c->prof_seen = 0;
         c->n_prof = 0;  // (re)start the record; hourly launches append until read or reset
         return CPM_OK;
     case CPM_OPT_ZONE_BLOCK:

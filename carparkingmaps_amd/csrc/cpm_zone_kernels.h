@@ -299,18 +299,20 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_hist(const uint32_t *__rest
     }
     for (int64_t i = i0 + 4 * n4 + threadIdx.x; i < i1; i += kSortBlock) atomicAdd(&bins[key[i] & kZoneMask], 1u);
     __syncthreads();
-    // ticket: this block's range inside every bucket.  Four returning atomics per thread are issued
-    // back to back (index clamped, count 0 out of range: straight-line code) and waited for once,
-    // instead of four dependent HBM-side round trips.
+    // ticket: this block's range inside every bucket.  The four returning atomics of a thread are
+    // issued before any result is stored, so they share one HBM-side round trip.  (Out-of-range
+    // lanes must NOT add 0 to a clamped address: at Z = 2357 that put 445k atomics on one word.)
     uint32_t *mybase = base + static_cast<size_t>(blockIdx.x) * Z;
     for (int zb = 0; zb < Z; zb += kSortBlock * 4) {
         uint32_t r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int z = zb + threadIdx.x + k * kSortBlock;
-            const int zc = min(z, Z - 1);
-            const uint32_t c = (z < Z) ? bins[zc] : 0u;
-            r[k] = atomicAdd(&cursor[zc], c);
+            r[k] = 0;
+            if (z < Z) {
+                const uint32_t c = bins[z];
+                if (c) r[k] = atomicAdd(&cursor[z], c);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

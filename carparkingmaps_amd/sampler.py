@@ -52,8 +52,9 @@ class Sampler:
     def set_kernel(self, kernel):
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
 
-    def set_profile(self, on=True):
-        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(bool(on))))
+    def set_profile(self, on=True, stride=1):
+        """hipEvents around every `stride`-th hourly sampler launch (0 / False: off)."""
+        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(stride) if on else 0))
 
     def set_stream(self, hip_stream):
         """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""

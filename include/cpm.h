@@ -63,7 +63,8 @@ extern "C" {
 #define CPM_KERNEL_ZONE_FUSED 3 /* same, persistent workgroups + fused counting-sort histogram */
 
 #define CPM_OPT_KERNEL 1
-#define CPM_OPT_PROFILE 2       /* 1: bracket every hourly kernel with hipEvents */
+#define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
+                                   pair costs ~10 us of stream bubbles, so sample); 0: off */
 #define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
 #define CPM_OPT_ZONE_CPT 4      /* tuning: cars per thread in the fused zone sampler */
 #define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
