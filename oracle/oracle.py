@@ -33,7 +33,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "liboracle.so")
+    so = os.environ.get("CPM_ORACLE_SO") or os.path.join(_HERE, "liboracle.so")  # e.g. liboracle_asan.so
     if not os.path.exists(so):
         build()
     L = C.CDLL(so)
