@@ -374,3 +374,67 @@ def test_sharded_sampler_stream_ordering(cpm, O):
             assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
     finally:
         ss.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_extreme_skew_everyone_to_one_zone(cpm, O, kernel):
+    """Every row is a point mass on zone 3: after one hour the whole fleet sits in one bucket
+    (one workgroup walks 200k cars; the fused kernel's 16-bit rank overflows and the blocking API
+    falls back by itself).  Counts stay bit-exact."""
+    Z, T, cpz = 64, 24, 3200
+    C = Z * cpz
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = np.zeros((Z, Z, T), order="F")
+    p_dest[:, 2, :] = 1.0
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(kernel)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+    assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
+    assert r["parking"][2, 5] > 0.9 * C
+
+
+def test_fused_kernel_reports_rank_overflow_in_the_status_word(cpm, O):
+    """The async form cannot fall back by itself: it raises the status word instead."""
+    import torch
+    from carparkingmaps_amd.distributed import split_counts
+    Z, T, cpz = 64, 24, 3200
+    C = Z * cpz
+    p_drive = np.ones((Z, T), order="F")
+    p_dest = np.zeros((Z, Z, T), order="F")
+    p_dest[:, 2, :] = 1.0
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(3)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        counts = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
+        s.resample_dev(SIM_SEED, counts.data_ptr())
+        s.sync()
+        assert int(counts[-1].item()) != 0
+        with pytest.raises(RuntimeError):
+            split_counts(counts, Z, T)
+        s.set_kernel(2)
+        s.resample_dev(SIM_SEED, counts.data_ptr())
+        s.sync()
+        pk, _, _ = split_counts(counts, Z, T)
+        assert (pk.sum(axis=0) == C).all() and pk[2, 1] == C
+
+
+def test_few_cars_per_zone_uses_the_car_kernel_and_matches(cpm, O):
+    """AUTO below 32 cars/zone (streaming every row would not pay): still bit-exact."""
+    Z, T, cpz = 300, 24, 5
+    C = Z * cpz
+    p_drive, p_dest = _tables(O, Z, T)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+    assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
