@@ -15,6 +15,7 @@
 #include "cpm_tables.h"
 #include "cpm_zone_kernels.h"
 #include "cpm_zone2_kernels.h"
+#include "cpm_zone3_kernels.h"
 
 namespace {
 
@@ -80,6 +81,7 @@ struct cpm_ctx {
     // zone-bucket path
     cpm::ZoneWork zw;
     cpm::Zone2Work zw2;
+    cpm::Zone3Work zw3;
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
@@ -234,6 +236,12 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_STRIDED) {
+        return cpm::zone3_resample(c->zw3, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
+                                   d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                                   g_last_error);
+    }
     if (pick_kernel(c) == CPM_KERNEL_ZONE_FUSED) {
         return cpm::zone2_resample(c->zw2, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                    static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
@@ -265,6 +273,7 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::zone_path_fits(c->Zp)) {
         int32_t rc = cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
@@ -359,6 +368,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_err);
     c->zw.release();
     c->zw2.release();
+    c->zw3.release();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -370,7 +380,7 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     CTX_TRY(c);
     switch (option) {
     case CPM_OPT_KERNEL:
-        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_FUSED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_STRIDED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE:
@@ -566,6 +576,7 @@ int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int6
     c->car_begin = car_begin;
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
     if (car_count > 0) {
         hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, car_begin,
                            car_count, cars_per_zone);
@@ -581,6 +592,7 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
     if (!c->have_state) return fail(CPM_ERR_STATE, "set_state: cpm_init_states first (defines the car range)");
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (!zones) return fail(CPM_ERR_ARG, "null zones");
     int64_t *d_z = nullptr;

@@ -110,14 +110,18 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample2(
     const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int H, int64_t car_begin,
     uint32_t step, uint64_t seed, unsigned long long *__restrict__ parking_t,
     unsigned long long *__restrict__ driving_t, const double *__restrict__ dm, int T, int t,
-    unsigned long long *tt_sum)
+    unsigned long long *tt_sum, uint32_t cap)
 {
     extern __shared__ double row[];  // 2^H doubles: the zone's CDF row as a search tree
     __shared__ uint32_t s_ndrive;
     __shared__ unsigned long long s_tt;
     const int z = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint32_t b = off[z], e = off[z + 1], n = e - b;
+    // cap == 0: exact layout, bucket z = [off[z], off[z+1]).  cap > 0: fixed-stride layout, bucket z =
+    // [z*cap, z*cap + off[z]) (off[] holds the bucket sizes).
+    const uint32_t b = cap ? static_cast<uint32_t>(z) * cap : off[z];
+    const uint32_t n = cap ? min(off[z], cap) : off[z + 1] - b;  // (an overflowed bucket is flagged by the sort; stay in range)
+    const uint32_t e = b + n;
     if (tid == 0) {
         parking_t[z] = n;  // every car present at hour t, drivers included (Appendix A-14)
         s_ndrive = 0;
@@ -510,7 +514,8 @@ inline void launch_zone_sample_b(ZoneWork &w, hipStream_t stream, bool travel, c
 inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
                                const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
                                uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
-                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row);
+                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row,
+                               uint32_t *dest_out = nullptr, uint32_t cap = 0);
 
 // ivp == false: the T-hour resample from the state in d_zone0 (left unchanged); counts -> d_counts.
 // ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps
@@ -607,8 +612,10 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
 inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
                                const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
                                uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
-                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row)
+                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row,
+                               uint32_t *dest_out, uint32_t cap)
 {
+    if (!dest_out) dest_out = w.dest;
 #ifdef CPM_DIAGNOSTIC
     if (w.ablate & 7) {  // diagnostic ablations, 256-thread form only
         switch (w.ablate & 7) {
@@ -636,11 +643,11 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
             attr_done = true;                                                                                            \
         }                                                                                                                \
         if (travel)                                                                                                      \
-            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, w.dest, pd, \
-                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum);           \
+            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
+                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, w.dest, pd, \
-                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum);           \
+            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
+                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
     } while (0)
         if (need <= 1) CPM_ZS2(1);
         else if (need <= 2) CPM_ZS2(2);

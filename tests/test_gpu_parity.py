@@ -8,7 +8,7 @@ from conftest import SIM_SEED, TABLE_SEED
 pytestmark = pytest.mark.gpu
 
 KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
-           pytest.param(3, id="zone_fused")]
+           pytest.param(3, id="zone_fused"), pytest.param(4, id="zone_strided")]
 
 
 def _tables(O, Z, T=24, seed=TABLE_SEED):
