@@ -53,6 +53,16 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  carparkingmaps_amd has no CPU fallback.")
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 (same
+    # SONAME as /opt/rocm's).  If this library is loaded first it pulls in the system copies, a later
+    # `import torch` adds the bundled ones, and the second runtime's initialisation can fail ("No HIP
+    # GPUs are available", seen after a long pytest session).  Importing torch first makes the dynamic
+    # loader bind libcpm_hip.so to the copy that is already mapped.  Without torch (e.g. under the Julia
+    # shim) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     i32, i64, u32, u64, dbl, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_void_p
     L.cpm_last_error.restype = C.c_char_p

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample(
 //     round trip per round of cars);
 //   * the row is written into LDS as a breadth-first search tree (see cpm_kernels.h);
 //   * every thread carries CPT cars through straight-line code: independent Philox chains and
-//     tree walks interleave (CPT LDS reads in flight per lane);
+//     tree walks interleave (CPT LDS reads in flight per lane); CPT = 2 measured best;
 //   * Bernoulli draw in integers (k <= floor(p * 2^53)).
 // NP: 16-B row pieces per thread (>= Zp / 2 / BLOCK).
 template <bool TRAVEL, int BLOCK, int NP, int CPT>
@@ -628,7 +628,7 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
         return;
     }
 #endif
-    if (w.tree) {  // default: tree layout, id prefetch, three cars per thread
+    if (w.tree) {  // default: tree layout, id prefetch, two cars per thread (measured at S4k: 1 -> 38.8 us, 2 -> 36.4, 3 -> 38.5, 4 -> 44.4)
         const int H = tree_height(Z);
         const size_t lds_tree = sizeof(double) * (size_t(1) << H);
         const int need = (Zp / 2 + 511) / 512;
@@ -636,17 +636,17 @@ inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, con
     do {                                                                                                                 \
         static bool attr_done = false;                                                                                   \
         if (!attr_done && lds_tree > 64 * 1024) {                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<false, 512, NPV, 3>),              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<false, 512, NPV, 2>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<true, 512, NPV, 3>),               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<true, 512, NPV, 2>),               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
             attr_done = true;                                                                                            \
         }                                                                                                                \
         if (travel)                                                                                                      \
-            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
+            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
                                cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 3>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
+            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
                                cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
     } while (0)
         if (need <= 1) CPM_ZS2(1);
