@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the model-selection grid of BASELINE.json configs[4] on one GPU: Melbourne-shaped synthetic
+datamatrix (Z = 2,357, 8.68 % dense), 1,000 cars/zone, N grid points; each point = table rebuild +
+24-hour resample with travel times from the cached post-IVP state.  Development tool."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import carparkingmaps_amd as cpm
+from carparkingmaps_amd import model_selection as ms
+from oracle import oracle as O   # synthetic input generator only
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--zones", type=int, default=2357)
+ap.add_argument("--cpz", type=int, default=1000)
+ap.add_argument("--points", type=int, default=32)
+args = ap.parse_args()
+Z, T, cpz = args.zones, 24, args.cpz
+C = Z * cpz
+t0 = time.perf_counter()
+dm, dist = O.synth_datamatrix(Z, T, 0x5EED7AB1E)
+print(f"synthetic datamatrix {dm.nbytes / 1e9:.2f} GB in {time.perf_counter() - t0:.1f} s", flush=True)
+rng = np.random.default_rng(1)
+with cpm.Sampler(Z, T) as s:
+    t0 = time.perf_counter()
+    s.set_datamatrix(dm, dist)
+    print(f"upload {time.perf_counter() - t0:.2f} s", flush=True)
+    s.build_p_drive(0.1, 0.9, 0.5, want=False)
+    s.build_p_dest(2, want=False)
+    s.init_states(C, cpz)
+    t0 = time.perf_counter()
+    s.solve_ivp(0x5EEDCA125, want=False)
+    print(f"IVP {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+    ev = ms.Evaluator(s, C, 0x5EEDCA125, rng.uniform(0, 1, T), rng.uniform(0, 1, (Z, T)), travel=True)
+    grid = ms.make_grid()[:: max(1, 256 // args.points)][: args.points]
+    ms.grid_sweep(ev, grid[:2])
+    t0 = time.perf_counter()
+    res = ms.grid_sweep(ev, grid)
+    dt = time.perf_counter() - t0
+    print(f"{len(grid)} grid points in {dt:.2f} s = {1e3 * dt / len(grid):.1f} ms/point "
+          f"({len(grid) * C * T / dt:.3e} car-steps/s incl. table rebuilds); "
+          f"256 points on 8 GPUs ~ {32 * dt / len(grid):.1f} s", flush=True)
+    print("sample:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in res[0].items()})
