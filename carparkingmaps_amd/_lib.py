@@ -22,7 +22,8 @@ SYMBOLS = [
 ]
 
 CPM_FLAG_TRAVEL = 1
-CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_FUSED, CPM_KERNEL_ZONE_STRIDED = 0, 1, 2, 3, 4
+CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_FUSED = 0, 1, 2, 3
+CPM_KERNEL_ZONE_STRIDED, CPM_KERNEL_ZONE_GROUPED = 4, 5
 CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
 
 _lib = None

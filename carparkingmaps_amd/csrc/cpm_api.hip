@@ -16,6 +16,7 @@
 #include "cpm_zone_kernels.h"
 #include "cpm_zone2_kernels.h"
 #include "cpm_zone3_kernels.h"
+#include "cpm_zone5_kernels.h"
 
 namespace {
 
@@ -82,6 +83,14 @@ struct cpm_ctx {
     cpm::ZoneWork zw;
     cpm::Zone2Work zw2;
     cpm::Zone3Work zw3;
+    cpm::Zone5Work zw5;
+    // AUTO demotes itself from the fixed-stride layouts to the exact one after the first overflow: the status
+    // word of every fixed-stride step is copied to pinned host memory behind the step and looked at, without
+    // waiting, when the next step is enqueued (the overflowed step itself is flagged in its own status word).
+    bool grouped_overflowed = false;
+    long long *h_status = nullptr;      // pinned
+    hipEvent_t status_ev = nullptr;
+    bool status_pending = false;
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
@@ -149,12 +158,16 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
     return CPM_OK;
 }
 
-// AUTO: the zone-bucketed LDS path when a CDF row fits in LDS and there are enough cars per zone
-// to amortise streaming every row once per hour; otherwise one thread per car.
+// AUTO: a zone-bucketed LDS path when a CDF row fits in LDS and there are enough cars per zone to
+// amortise streaming every row once per hour (the grouped fixed-stride form while no bucket has ever
+// outgrown its region in this context, else the exact layout); otherwise one thread per car.
 int pick_kernel(const cpm_ctx *c)
 {
     if (c->kernel != CPM_KERNEL_AUTO) return c->kernel;
-    if (cpm::zone_path_fits(c->Zp) && c->n >= 32 * c->Z && c->n < (int64_t(1) << 32)) return CPM_KERNEL_ZONE_LDS;
+    if (cpm::zone_path_fits(c->Zp) && c->n >= 32 * c->Z && c->n < (int64_t(1) << 32)) {
+        if (!c->grouped_overflowed && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z))) return CPM_KERNEL_ZONE_GROUPED;
+        return CPM_KERNEL_ZONE_LDS;
+    }
     return CPM_KERNEL_CAR;
 }
 
@@ -233,10 +246,30 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
     if (travel && !c->have_dm) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
+    if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
+        c->status_pending = false;
+        if (*c->h_status != 0) c->grouped_overflowed = true;
+    }
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) {
+        if (!cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z)))
+            return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
+        int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                         static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
+                                         d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                                         g_last_error);
+        if (rc == CPM_OK && c->h_status && !c->status_pending) {
+            if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipEventRecord(c->status_ev, c->stream) == hipSuccess)
+                c->status_pending = true;
+        }
+        return rc;
+    }
     if (pick_kernel(c) == CPM_KERNEL_ZONE_STRIDED) {
+        if (!cpm::zone3_path_fits(c->Zp, c->n, static_cast<int>(c->Z)))
+            return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_STRIDED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
         return cpm::zone3_resample(c->zw3, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                    static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
                                    d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
@@ -274,6 +307,7 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
+    c->zw5.base.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::zone_path_fits(c->Zp)) {
         int32_t rc = cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
@@ -343,6 +377,9 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(long long));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming);
+    if (e == hipSuccess) *c->h_status = 0;
     if (e != hipSuccess) {
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -369,6 +406,9 @@ int32_t cpm_destroy(cpm_ctx *c)
     c->zw.release();
     c->zw2.release();
     c->zw3.release();
+    c->zw5.release();
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->status_ev) (void)hipEventDestroy(c->status_ev);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -380,7 +420,7 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     CTX_TRY(c);
     switch (option) {
     case CPM_OPT_KERNEL:
-        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_STRIDED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE:
@@ -577,6 +617,7 @@ int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int6
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
+    c->zw5.base.buckets0_valid = false;
     if (car_count > 0) {
         hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, car_begin,
                            car_count, cars_per_zone);
@@ -593,6 +634,7 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
     c->zw.buckets0_valid = false;
     c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
+    c->zw5.base.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (!zones) return fail(CPM_ERR_ARG, "null zones");
     int64_t *d_z = nullptr;
@@ -665,6 +707,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (status != 0) {
+            c->grouped_overflowed = true;
             c->kernel = CPM_KERNEL_ZONE_LDS;
             rc = resample_enqueue(c, seed, flags, c->d_counts);
         }

@@ -1,0 +1,473 @@
+// cpm_zone5_kernels.h -- CPM_KERNEL_ZONE_GROUPED: fixed-stride buckets, stayers kept by the sampler,
+// drivers placed in two levels so that the final id writes merge in one XCD's L2.
+//
+// Why (profiles/round1_notes.md): in both earlier zone paths the hourly regrouping costs more than
+// the sampling (47 us against 36 us at S4k), and its floor is the ~2 M random 4-byte id writes of an
+// hour: each one leaves its L2 as a masked 32-byte sector write (WRITE_SIZE 68 MB for 16 MB of
+// payload), because the arrivals of one bucket come from every workgroup on every XCD.  Here
+//   * a car that does not drive never leaves its zone: the sampler compacts the stayers straight into
+//     the zone's fixed region of next hour's id array (coalesced), and they never enter the sort;
+//   * the sampler workgroup sorts its drivers by destination GROUP (kGroups groups of consecutive
+//     zones) inside its own fixed region of a driver array D: rank per group from LDS atomics, group
+//     offsets from a 32-wide wave scan, (id, dest) pairs written at D[z*cap + off_g + rank], and the
+//     33 offsets of the zone published with plain stores.  No global atomic, no round trip.
+//     (A first version appended to per-group global lists with a ticket per workgroup: all Z
+//     workgroups hit the same 32 counters and same-address atomics are served one at a time, 64 us
+//     per hour; replicated 32x it still exposed one atomic round trip per workgroup, 51 us.)
+//   * k_zone5_place then takes one group per 8 blocks -- blockIdx = j * kGroups + g, so the blocks of a
+//     group share blockIdx % 8, i.e. one XCD and one L2.  A block gathers the group-g segments of an
+//     eighth of the origin zones (~16 pairs = one 128-B line each) and moves the ids into their
+//     buckets.  All writes to a bucket now come from one L2, where they merge before they leave.
+// Bucket sizes (= next hour's parking histogram) are the ticket counters, as in cpm_zone3_kernels.h.
+// Overflow of a bucket region raises bit 1 of the status word; no out-of-range store is issued; the
+// caller repeats the step on the exact layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/cpm.h"
+#include "cpm_kernels.h"
+#include "cpm_zone_kernels.h"
+#include "cpm_zone3_kernels.h"
+
+namespace cpm {
+
+constexpr int kGroups = 32;          // destination groups; zones per group <= kMaxZonesPerGroup
+constexpr int kBlocksPerGroup = 8;   // blocks of k_zone5_place per group (all on one XCD)
+constexpr int kMaxZonesPerGroup = 512;
+constexpr int kRankShift = 14;       // per-slot record: dest (14 bits) | rank in (workgroup, group) << 14 | drive << 31
+constexpr uint32_t kDest14 = (1u << kRankShift) - 1u;
+
+struct Zone5Args {
+    const uint32_t *ids;      // [Z*cap] this hour's buckets
+    const uint32_t *cnt;      // [Z] their sizes
+    uint32_t *rec;            // [Z*cap] scratch: per-slot record for cars beyond the register-resident ones
+    const double *pdrive_t, *cdf_t, *dm;
+    uint32_t *ids_next;       // [Z*cap]
+    uint32_t *cnt_next;       // [Z]: set to the number of stayers here, drivers are added by k_zone5_place
+    uint2 *D;                 // [Z*cap] (id, dest) of this hour's drivers: zone z's, sorted by destination group, at z*cap
+    uint32_t *offz;           // [Z][kGroups+1] start of every group's run inside the zone's region of D
+    unsigned long long *parking_t, *driving_t, *tt_sum, *status;
+    int Z, Zp, H, T, t, zpg;
+    uint32_t cap, step, gmagic;  // gmagic: dest / zpg == (dest * gmagic) >> 24 for dest < 2^14
+    int64_t car_begin;
+    uint64_t seed;
+};
+
+template <bool TRAVEL, int BLOCK, int NP, int CPT>
+__global__ __launch_bounds__(BLOCK) void k_zone5_sample(Zone5Args a)
+{
+    extern __shared__ double row[];  // 2^H doubles: the zone's CDF row as a search tree
+    __shared__ uint32_t s_ndrive, s_nstay;
+    __shared__ unsigned long long s_tt;
+    __shared__ uint32_t gb[kGroups];  // drivers of this workgroup per destination group, then their run's start
+    const int Z = a.Z, Zp = a.Zp, H = a.H;
+    const int z = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t cap = a.cap;
+    const uint32_t b = static_cast<uint32_t>(z) * cap;
+    const uint32_t n = min(a.cnt[z], cap);
+    if (tid == 0) {
+        a.parking_t[z] = n;
+        s_ndrive = 0;
+        s_nstay = 0;
+        s_tt = 0;
+    }
+    if (tid < kGroups) gb[tid] = 0;
+    if (n == 0) {
+        if (tid == 0) a.cnt_next[z] = 0;
+        if (tid <= kGroups) a.offz[static_cast<size_t>(z) * (kGroups + 1) + tid] = 0;
+        return;
+    }
+    uint32_t id[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) id[c] = a.ids[b + min(static_cast<uint32_t>(tid + c * BLOCK), n - 1)];
+    double2 pc[NP];
+    const double2 *src = reinterpret_cast<const double2 *>(a.cdf_t + static_cast<size_t>(z) * Zp);
+#pragma unroll
+    for (int m = 0; m < NP; ++m) pc[m] = src[min(tid + m * BLOCK, Zp / 2 - 1)];
+    const long long thr = bernoulli_threshold(a.pdrive_t[z]);
+    const int P = 1 << H;
+    for (int r = Z + tid; r < P; r += BLOCK) {
+        int tz = __builtin_ctz(static_cast<unsigned>(r));
+        row[(1u << (H - 1 - tz)) + (static_cast<unsigned>(r) >> (tz + 1))] = __builtin_huge_val();
+    }
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        int j = tid + m * BLOCK;
+        if (2 * j < Zp) {
+            uint32_t el = 2 * j;
+            if (el < static_cast<uint32_t>(Z)) row[eytz_pos(el, Z, H)] = pc[m].x;
+            if (el + 1 < static_cast<uint32_t>(Z)) row[eytz_pos(el + 1, Z, H)] = pc[m].y;
+        }
+    }
+    __syncthreads();
+    const double last = row[0];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t nd = 0;
+    long long tt = 0;
+    uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
+
+    // one car: stayer -> compacted into next hour's bucket of this zone; driver -> ranked inside its
+    // destination group.  Returns the record dest | rank << 14 | drive << 31.
+    auto place = [&](uint32_t idc, bool valid, bool drive, uint32_t dest) -> uint32_t {
+        const unsigned long long mS = __ballot(valid && !drive);
+        uint32_t bS = 0;
+        if (lane == 0 && mS) bS = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(mS)));
+        bS = __shfl(bS, 0, 64);
+        if (valid && !drive) stay_out[bS + static_cast<uint32_t>(__popcll(mS & below))] = idc;
+        uint32_t rec = dest;
+        if (drive) {
+            const uint32_t rank = atomicAdd(&gb[(dest * a.gmagic) >> 24], 1u);
+            rec = dest | (rank << kRankShift) | kDriveBit;
+        }
+        return rec;
+    };
+
+    uint32_t rec[CPT];
+    {  // CPT cars per thread, straight line
+        bool valid[CPT], drive[CPT], any_search = false;
+        uint32_t dest[CPT];
+        double ue[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
+            long long kb;
+            double uc;
+            car_draws(a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step, kb, uc);
+            drive[c] = valid[c] && (kb <= thr);
+            dest[c] = z;
+            ue[c] = clamp_u(uc, last);
+            any_search |= drive[c] && last != 0.0;
+        }
+        if (__any(any_search)) {
+            uint32_t i[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) i[c] = 1;
+            for (int l = 0; l < H; ++l) {
+                double k[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) k[c] = row[i[c]];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) i[c] = 2 * i[c] + (k[c] < ue[c] ? 1u : 0u);
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (drive[c] && last != 0.0) dest[c] = eytz_decode(i[c], Z, H);
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            rec[c] = place(id[c], valid[c], drive[c], dest[c]);
+            if (drive[c]) {
+                ++nd;
+                if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step);
+            }
+        }
+    }
+    for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
+        const uint32_t q = q0 + tid;
+        const bool valid = q < n;
+        const uint32_t idx = valid ? a.ids[b + q] : 0u;
+        const uint64_t car = static_cast<uint64_t>(a.car_begin) + idx;
+        long long kb;
+        double uc;
+        car_draws(a.seed, car, a.step, kb, uc);
+        const bool drive = valid && (kb <= thr);
+        uint32_t dest = z;
+        if (drive) {
+            if (last != 0.0) {
+                const double u1 = clamp_u(uc, last);
+                uint32_t i = 1;
+                for (int l = 0; l < H; ++l) i = 2 * i + (row[i] < u1 ? 1u : 0u);
+                dest = eytz_decode(i, Z, H);
+            }
+            if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest, a.seed, car, a.step);
+            ++nd;
+        }
+        const uint32_t r = place(idx, valid, drive, dest);
+        if (valid) a.rec[b + q] = r;  // needed again after the ticket
+    }
+    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+    if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
+    if (TRAVEL) {
+        for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
+        if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
+    }
+    __syncthreads();  // group counts, stayer count final
+    // group offsets inside this zone's region of D: exclusive scan of the 32 group counts (one wave)
+    if (tid < 64) {
+        const uint32_t c = (tid < kGroups) ? gb[tid] : 0u;
+        uint32_t incl = c;
+        for (int o = 1; o < kGroups; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        const uint32_t total = __shfl(incl, kGroups - 1, 64);
+        if (tid < kGroups) gb[tid] = incl - c;
+        if (tid <= kGroups) a.offz[static_cast<size_t>(z) * (kGroups + 1) + tid] = (tid < kGroups) ? incl - c : total;
+    }
+    if (tid == 0) {
+        a.driving_t[z] = s_ndrive;
+        a.cnt_next[z] = s_nstay;  // k_zone5_place adds the arrivals
+        if (TRAVEL && s_tt) atomicAdd(a.tt_sum, s_tt);
+    }
+    __syncthreads();
+    // drivers -> their group's list
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+        if (rec[c] & kDriveBit) {
+            const uint32_t dest = rec[c] & kDest14, g = (dest * a.gmagic) >> 24;
+            const uint32_t p = gb[g] + ((rec[c] & kZoneMask) >> kRankShift);
+            a.D[static_cast<size_t>(b) + p] = make_uint2(id[c], dest);
+        }
+    for (uint32_t q = CPT * BLOCK + tid; q < n; q += BLOCK) {
+        const uint32_t r = a.rec[b + q];
+        if (r & kDriveBit) {
+            const uint32_t dest = r & kDest14, g = (dest * a.gmagic) >> 24;
+            const uint32_t p = gb[g] + ((r & kZoneMask) >> kRankShift);
+            a.D[static_cast<size_t>(b) + p] = make_uint2(a.ids[b + q], dest);
+        }
+    }
+}
+
+// Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the kBlocksPerGroup
+// blocks of a group share blockIdx % 8 (one XCD, one L2; speed only, never correctness).  Block (g, j)
+// gathers the group-g runs of the origin zones [j*zps, (j+1)*zps); 16 lanes per run.
+constexpr int kPlaceBlock = 1024;
+constexpr int kPlaceSeg = kPlaceBlock / 16;  // runs in flight per pass
+
+__global__ __launch_bounds__(kPlaceBlock) void k_zone5_place(const uint2 *__restrict__ D, const uint32_t *__restrict__ offz,
+                                                             int zpg, int zps, int Z, uint32_t cap,
+                                                             uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
+                                                             unsigned long long *status)
+{
+    __shared__ uint32_t bins[kMaxZonesPerGroup];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x % kGroups, j = blockIdx.x / kGroups;
+    const int zg0 = g * zpg;
+    const int nzl = max(0, min(zpg, Z - zg0));
+    const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
+    const int sub = tid >> 4, l16 = tid & 15;
+    for (int k = tid; k < kMaxZonesPerGroup; k += kPlaceBlock) bins[k] = 0;
+    __syncthreads();
+    // Every thread owns the lane-l16 pair of kRuns runs (origin zones zs0 + sub + k * kPlaceSeg): descriptors
+    // and pairs are loaded once, all loads in flight together, and kept in registers across the ticket.
+    // Pairs beyond the 16th of a run (runs average ~16) are re-read in pass 2.
+    constexpr int kRuns = 8;  // zps <= kRuns * kPlaceSeg = 512 origin zones per block
+    uint32_t o0[kRuns], o1[kRuns];
+    uint2 v[kRuns];
+#pragma unroll
+    for (int k = 0; k < kRuns; ++k) {
+        const int zs = zs0 + sub + k * kPlaceSeg;
+        const int zc = min(zs, zs1 - 1);
+        o0[k] = offz[static_cast<size_t>(zc) * (kGroups + 1) + g];
+        o1[k] = offz[static_cast<size_t>(zc) * (kGroups + 1) + g + 1];
+        if (zs >= zs1) o1[k] = o0[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kRuns; ++k) {
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        v[k] = make_uint2(0u, static_cast<uint32_t>(zg0));
+        if (o0[k] + l16 < o1[k]) v[k] = D[static_cast<size_t>(zc) * cap + o0[k] + l16];
+    }
+    // pass 1: histogram of the destinations over the group's zones
+#pragma unroll
+    for (int k = 0; k < kRuns; ++k) {
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        if (o0[k] + l16 < o1[k]) atomicAdd(&bins[v[k].y - zg0], 1u);
+        for (uint32_t i = o0[k] + l16 + 16; i < o1[k]; i += 16) atomicAdd(&bins[D[static_cast<size_t>(zc) * cap + i].y - zg0], 1u);
+    }
+    __syncthreads();
+    if (tid < nzl) {  // ticket: this block's range inside each bucket of the group
+        const uint32_t c = bins[tid];
+        uint32_t base = 0;
+        if (c) {
+            base = atomicAdd(&cnt_next[zg0 + tid], c);
+            if (base + c > cap) atomicOr(status, 2ull);
+        }
+        bins[tid] = base;
+    }
+    __syncthreads();
+    // pass 2: the ids move
+#pragma unroll
+    for (int k = 0; k < kRuns; ++k) {
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        if (o0[k] + l16 < o1[k]) {
+            const uint32_t p = atomicAdd(&bins[v[k].y - zg0], 1u);
+            if (p < cap) ids_next[static_cast<size_t>(v[k].y) * cap + p] = v[k].x;
+        }
+        for (uint32_t i = o0[k] + l16 + 16; i < o1[k]; i += 16) {
+            const uint2 w = D[static_cast<size_t>(zc) * cap + i];
+            const uint32_t p = atomicAdd(&bins[w.y - zg0], 1u);
+            if (p < cap) ids_next[static_cast<size_t>(w.y) * cap + p] = w.x;
+        }
+    }
+}
+
+struct Zone5Work {
+    Zone3Work base;  // bucket arrays, cached initial bucketing, sampler launcher state
+    uint2 *D = nullptr;          // [Z*cap]
+    uint32_t *offz = nullptr;    // [Z][kGroups+1]
+    uint32_t gmagic = 0;
+    int zpg = 0, zps = 0;
+    int64_t n = 0;
+    int Z = 0, T = 0;
+
+    void release()
+    {
+        base.release();
+        if (D) (void)hipFree(D);
+        if (offz) (void)hipFree(offz);
+        D = nullptr;
+        offz = nullptr;
+        n = 0;
+    }
+
+    hipError_t ensure(int64_t n_, int Z_, int T_, int cu_count)
+    {
+        hipError_t e = base.ensure(n_, Z_, T_, cu_count);
+        if (e != hipSuccess) return e;
+        if (n_ == n && Z_ == Z && T_ == T && D) return hipSuccess;
+        if (D) (void)hipFree(D);
+        if (offz) (void)hipFree(offz);
+        D = nullptr;
+        offz = nullptr;
+        n = n_;
+        Z = Z_;
+        T = T_;
+        zpg = (Z + kGroups - 1) / kGroups;
+        zps = (Z + kBlocksPerGroup - 1) / kBlocksPerGroup;
+        gmagic = (1u << 24) / static_cast<uint32_t>(zpg) + 1u;  // exact for dest < 2^14 (2^24 / zpg >= 2^15)
+        e = hipMalloc(&D, sizeof(uint2) * static_cast<size_t>(Z) * base.cap);
+        if (e == hipSuccess) e = hipMalloc(&offz, sizeof(uint32_t) * static_cast<size_t>(Z) * (kGroups + 1));
+        if (e != hipSuccess) release();
+        return e;
+    }
+};
+
+inline bool zone5_path_fits(int Zp, int64_t n, int Z)
+{
+    const int64_t mean = (n + Z - 1) / Z;
+    return zone3_path_fits(Zp, n, Z) && Z <= (1 << kRankShift) && (Z + kGroups - 1) / kGroups <= kMaxZonesPerGroup &&
+           (Z + kBlocksPerGroup - 1) / kBlocksPerGroup <= 8 * kPlaceSeg &&
+           n < (int64_t(1) << 30) && std::max<int64_t>(4 * mean, 1024) + 64 <= (int64_t(1) << (31 - kRankShift));  // rank field
+}
+
+template <bool TRAVEL, int NP>
+inline void zone5_launch_np(const Zone5Args &a, size_t lds, hipStream_t stream)
+{
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone5_sample<TRAVEL, 512, NP, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_zone5_sample<TRAVEL, 512, NP, 2>), dim3(a.Z), dim3(512), lds, stream, a);
+}
+
+template <bool TRAVEL>
+inline void zone5_launch(const Zone5Args &a, size_t lds, hipStream_t stream)
+{
+    const int need = (a.Zp / 2 + 511) / 512;
+    if (need <= 1) zone5_launch_np<TRAVEL, 1>(a, lds, stream);
+    else if (need <= 2) zone5_launch_np<TRAVEL, 2>(a, lds, stream);
+    else if (need <= 4) zone5_launch_np<TRAVEL, 4>(a, lds, stream);
+    else if (need <= 8) zone5_launch_np<TRAVEL, 8>(a, lds, stream);
+    else zone5_launch_np<TRAVEL, 16>(a, lds, stream);
+}
+
+// The T-hour resample from the state in d_zone0 (left unchanged); status word as in zone3_resample.
+template <typename F1, typename F2>
+int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
+                       int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
+                       const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err)
+{
+    auto hip_fail = [&](hipError_t e, const char *what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
+    };
+    hipError_t e = w5.ensure(n, Z, T, cu_count);
+    if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
+    Zone3Work &w = w5.base;
+    const size_t lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
+    if (!w.attrs_set) {
+        if (lds_bins > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone3_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds_bins));
+        w.attrs_set = true;
+    }
+    unsigned long long *parking = reinterpret_cast<unsigned long long *>(d_counts);
+    unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
+    unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
+    unsigned long long *status = tt_sum + 1;
+    e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
+    if (e != hipSuccess) return hip_fail(e, "memset counters");
+    if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
+        const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
+        if ((e = hipMemsetAsync(w.cnt0, 0, sizeof(uint32_t) * Z, stream)) != hipSuccess) return hip_fail(e, "memset cnt0");
+        hipLaunchKernelGGL(k_zone3_sort<false>, dim3(w.nb0), dim3(kSort3Block), lds_bins, stream, d_zone0,
+                           static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), 0, n, chunk, Z, w.cap,
+                           w.cnt0, w.ids0, status);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
+        w.buckets0_valid = true;
+    }
+    const int H = tree_height(Z);
+    const size_t lds_tree = sizeof(double) * (size_t(1) << H);
+    Zone5Args a;
+    a.rec = w.dest;
+    a.dm = d_dm;
+    a.D = w5.D;
+    a.offz = w5.offz;
+    a.tt_sum = tt_sum;
+    a.status = status;
+    a.Z = Z;
+    a.Zp = Zp;
+    a.H = H;
+    a.T = T;
+    a.zpg = w5.zpg;
+    a.cap = w.cap;
+    a.gmagic = w5.gmagic;
+    a.car_begin = car_begin;
+    a.seed = seed;
+    const uint32_t *ids = w.ids0, *cnt = w.cnt0;
+    for (int t = 0; t < T; ++t) {
+        const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
+        const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
+        const uint32_t step = static_cast<uint32_t>(T - 1 + t);
+        if (t + 1 == T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83): counts only
+            prof_begin(t);
+            launch_zone_sample(w.sampler, stream, travel, ids, cnt, pd, cdf, Z, Zp, car_begin, step, seed,
+                               parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum, 0,
+                               w.dest, w.cap);
+            prof_end(t);
+        } else {
+            uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * Z;
+            uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
+            a.ids = ids;
+            a.cnt = cnt;
+            a.pdrive_t = pd;
+            a.cdf_t = cdf;
+            a.ids_next = ids_next;
+            a.cnt_next = cnt_next;
+            a.parking_t = parking + static_cast<size_t>(t) * Z;
+            a.driving_t = driving + static_cast<size_t>(t) * Z;
+            a.t = t;
+            a.step = step;
+            prof_begin(t);
+            if (travel) zone5_launch<true>(a, lds_tree, stream);
+            else zone5_launch<false>(a, lds_tree, stream);
+            prof_end(t);
+            hipLaunchKernelGGL(k_zone5_place, dim3(kGroups * kBlocksPerGroup), dim3(kPlaceBlock), 0, stream, w5.D, w5.offz, w5.zpg,
+                               w5.zps, Z, w.cap, cnt_next, ids_next, status);
+            ids = ids_next;
+            cnt = cnt_next;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
+    }
+    return CPM_OK;
+}
+
+}  // namespace cpm

@@ -61,6 +61,7 @@ extern "C" {
 #define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
 #define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS (three launches per hour) */
 #define CPM_KERNEL_ZONE_FUSED 3 /* same, persistent workgroups + fused counting-sort histogram (experimental) */
+#define CPM_KERNEL_ZONE_GROUPED 5 /* fixed-stride buckets; stayers kept by the sampler, drivers placed per destination group */
 #define CPM_KERNEL_ZONE_STRIDED 4 /* zone path with fixed-stride buckets: the counting sort is one kernel per hour */
 
 #define CPM_OPT_KERNEL 1

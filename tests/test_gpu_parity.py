@@ -8,7 +8,8 @@ from conftest import SIM_SEED, TABLE_SEED
 pytestmark = pytest.mark.gpu
 
 KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
-           pytest.param(3, id="zone_fused"), pytest.param(4, id="zone_strided")]
+           pytest.param(3, id="zone_fused"), pytest.param(4, id="zone_strided"),
+           pytest.param(5, id="zone_grouped")]
 
 
 def _tables(O, Z, T=24, seed=TABLE_SEED):

@@ -33,7 +33,7 @@ for cfg in args.configs.split(","):
     kern, block, abl = parts[:3]
     cpt = parts[3] if len(parts) > 3 else "3"
     _lib.check(L.cpm_set_option(s._h, 4, int(cpt)))
-    s.set_kernel({"car": 1, "zone": 2, "fused": 3, "strided": 4}[kern])
+    s.set_kernel({"car": 1, "zone": 2, "fused": 3, "strided": 4, "grouped": 5}[kern])
     _lib.check(L.cpm_set_option(s._h, 3, int(block)))
     _lib.check(L.cpm_set_option(s._h, 100, int(abl)))
     r = s.resample(0x5EEDCA125)
