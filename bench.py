@@ -81,7 +81,7 @@ def pmc_traffic(kernel, Z, cars_per_gpu):
         return None, None
     name = {0: "k_zone5_sample", 5: "k_zone5_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car",
             3: "k_zone2_sample"}[kernel]
-    for f in ("round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
+    for f in ("round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             for k, v in json.load(open(path)).items():
