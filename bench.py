@@ -79,8 +79,7 @@ def pmc_traffic(kernel, Z, cars_per_gpu):
     MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  None when no run matches."""
     if Z != 4096 or cars_per_gpu != 4096000:
         return None, None
-    name = {0: "k_zone5_sample", 5: "k_zone5_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car",
-            3: "k_zone2_sample"}[kernel]
+    name = {0: "k_zone5_sample", 5: "k_zone5_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car"}[kernel]
     for f in ("round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
@@ -97,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--zones", type=int, default=4096)
     ap.add_argument("--cars-per-zone", type=int, default=1000, help="per GPU (weak scaling)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 3 zone_fused, 4 zone_strided, 5 zone_grouped")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 4 zone_strided, 5 zone_grouped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -219,7 +218,7 @@ def main():
             "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
-                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 3: "zone_fused", 4: "zone_strided",
+                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 4: "zone_strided",
                                   5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " after overflow fallback"),
                        "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),

@@ -6,7 +6,8 @@ The compute lives in csrc/libcpm_hip.so (hand-written HIP, C ABI in include/cpm.
 no CPU fallback; importing the package works without a GPU, computing does not.
 """
 from . import _lib
-from ._lib import CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS, CpmError
+from ._lib import (CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_GROUPED, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_STRIDED,
+                   CpmError)
 from .sampler import Sampler, device_count, device_info
 from .reference_api import (Params, averagedrivingtime, correctparameters, createpdestin, createpdrive,
                             initializestates, params, release, resampling, run_dataset, saveresults,
@@ -14,7 +15,7 @@ from .reference_api import (Params, averagedrivingtime, correctparameters, creat
 
 __all__ = [
     "Sampler", "device_count", "device_info", "CpmError", "CPM_KERNEL_AUTO", "CPM_KERNEL_CAR",
-    "CPM_KERNEL_ZONE_LDS", "Params", "params", "createpdrive", "createpdestin", "initializestates",
+    "CPM_KERNEL_ZONE_LDS", "CPM_KERNEL_ZONE_STRIDED", "CPM_KERNEL_ZONE_GROUPED", "Params", "params", "createpdrive", "createpdestin", "initializestates",
     "solveinitialvalueproblem", "resampling", "averagedrivingtime", "correctparameters", "saveresults",
     "zone_hour_counts", "run_dataset", "release",
 ]

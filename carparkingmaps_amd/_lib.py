@@ -18,11 +18,10 @@ SYMBOLS = [
     "cpm_build_p_drive", "cpm_build_p_dest", "cpm_get_p_drive", "cpm_get_cdf_row", "cpm_init_states",
     "cpm_set_state", "cpm_get_state", "cpm_solve_ivp", "cpm_resample", "cpm_resample_dev",
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
-    "cpm_debug_cycles",
 ]
 
 CPM_FLAG_TRAVEL = 1
-CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_FUSED = 0, 1, 2, 3
+CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
 CPM_KERNEL_ZONE_STRIDED, CPM_KERNEL_ZONE_GROUPED = 4, 5
 CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
 
@@ -92,7 +91,6 @@ def load():
     L.cpm_synth_tables.argtypes = [vp, u64]
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
-    L.cpm_debug_cycles.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("cpm_last_error",):

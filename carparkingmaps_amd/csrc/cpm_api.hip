@@ -14,7 +14,6 @@
 #include "cpm_kernels.h"
 #include "cpm_tables.h"
 #include "cpm_zone_kernels.h"
-#include "cpm_zone2_kernels.h"
 #include "cpm_zone3_kernels.h"
 #include "cpm_zone5_kernels.h"
 
@@ -81,7 +80,6 @@ struct cpm_ctx {
     int *d_err = nullptr;
     // zone-bucket path
     cpm::ZoneWork zw;
-    cpm::Zone2Work zw2;
     cpm::Zone3Work zw3;
     cpm::Zone5Work zw5;
     // AUTO demotes itself from the fixed-stride layouts to the exact one after the first overflow: the status
@@ -275,12 +273,6 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
                                    d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
                                    g_last_error);
     }
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_FUSED) {
-        return cpm::zone2_resample(c->zw2, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
-                                   d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                   g_last_error);
-    }
     if (pick_kernel(c) == CPM_KERNEL_ZONE_LDS) {
         return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
@@ -305,7 +297,6 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "solve_ivp: p_drive / p_dest not set");
     if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
     c->zw.buckets0_valid = false;
-    c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
     c->zw5.base.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
@@ -404,7 +395,6 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_counts);
     dfree(c->d_err);
     c->zw.release();
-    c->zw2.release();
     c->zw3.release();
     c->zw5.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -420,7 +410,7 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     CTX_TRY(c);
     switch (option) {
     case CPM_OPT_KERNEL:
-        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_GROUPED || value == 3) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE:
@@ -434,15 +424,9 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         if (value != 0 && value != 256 && value != 512) return fail(CPM_ERR_ARG, "zone block %lld", (long long)value);
         c->zw.tree = (value == 0);
         if (value) c->zw.block = static_cast<int>(value);
-        c->zw2.block = static_cast<int>(value);
-        return CPM_OK;
-    case CPM_OPT_ZONE_CPT:
-        if (value < 1 || value > 8) return fail(CPM_ERR_ARG, "cars per thread %lld", (long long)value);
-        c->zw2.cpt = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_ABLATE:
         c->zw.ablate = static_cast<int>(value);
-        c->zw2.ablate = static_cast<int>(value);
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown option %d", option);
@@ -615,7 +599,6 @@ int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int6
     c->cpz = cars_per_zone;
     c->car_begin = car_begin;
     c->zw.buckets0_valid = false;
-    c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
     c->zw5.base.buckets0_valid = false;
     if (car_count > 0) {
@@ -632,7 +615,6 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
     CTX_TRY(c);
     if (!c->have_state) return fail(CPM_ERR_STATE, "set_state: cpm_init_states first (defines the car range)");
     c->zw.buckets0_valid = false;
-    c->zw2.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
     c->zw5.base.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
@@ -702,7 +684,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
     if (compat) c->kernel = CPM_KERNEL_CAR;  // the per-hour records of every car are kept by this path
     int32_t rc = resample_enqueue(c, seed, flags, c->d_counts);
     size_t zt = static_cast<size_t>(c->Z * c->T);
-    if (rc == CPM_OK) {  // rank overflow in the fused zone path (pathological skew): redo with the unfused one
+    if (rc == CPM_OK) {  // a fixed-stride bucket outgrew its region (pathological skew): redo on the exact layout
         int64_t status = 0;
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -757,17 +739,6 @@ int32_t cpm_last_kernel_ms(cpm_ctx *c, float *ms_out, int32_t cap, int32_t *n_ou
     int n = std::min<int>(c->n_prof, cap);
     for (int k = 0; k < n; ++k) HIP_TRY(hipEventElapsedTime(&ms_out[k], c->ev[2 * k], c->ev[2 * k + 1]));
     *n_out = n;
-    return CPM_OK;
-}
-
-int32_t cpm_debug_cycles(cpm_ctx *c, uint64_t *out8)
-{
-    CTX_TRY(c);
-    if (!out8) return fail(CPM_ERR_ARG, "null out8");
-    if (!c->zw2.dbg) return fail(CPM_ERR_STATE, "no diagnostic buffer");
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out8, c->zw2.dbg, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(c->zw2.dbg, 0, sizeof(uint64_t) * 8));
     return CPM_OK;
 }
 

@@ -59,8 +59,8 @@ extern "C" {
 /* search kernels (cpm_set_option CPM_OPT_KERNEL) */
 #define CPM_KERNEL_AUTO 0
 #define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
-#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS (three launches per hour) */
-#define CPM_KERNEL_ZONE_FUSED 3 /* same, persistent workgroups + fused counting-sort histogram (experimental) */
+#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS; exact (packed) bucket layout, three launches per hour */
+/* 3 was an experimental persistent-workgroup form, removed (profiles/round1_notes.md) */
 #define CPM_KERNEL_ZONE_GROUPED 5 /* fixed-stride buckets; stayers kept by the sampler, drivers placed per destination group */
 #define CPM_KERNEL_ZONE_STRIDED 4 /* zone path with fixed-stride buckets: the counting sort is one kernel per hour */
 
@@ -68,7 +68,6 @@ extern "C" {
 #define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
                                    pair costs ~10 us of stream bubbles, so sample); 0: off */
 #define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
-#define CPM_OPT_ZONE_CPT 4      /* tuning: cars per thread in the fused zone sampler */
 #define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;
@@ -140,10 +139,10 @@ int32_t cpm_resample(cpm_ctx *ctx, uint64_t seed, uint32_t flags, int64_t *parki
 /* enqueue the fused resample on the context's stream and return without synchronising.
  * d_counts: DEVICE pointer to int64[2*T*Z + 2] = parking[T][Z] | driving[T][Z] | sum_tt_q16 |
  * status, zeroed and filled by the call (ready for one all-reduce).  status != 0 (after the
- * reduce: on any rank) means the fused zone kernel met a destination bucket it cannot index
- * (more than 65535 drivers from one workgroup to one zone); the counts are then invalid and the
+ * reduce: on any rank) means a fixed-stride zone kernel met a bucket that outgrew its region
+ * (more than 4x the mean zone population in one zone); the counts are then invalid and the
  * caller repeats the step with CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR.  cpm_resample does this
- * by itself. */
+ * by itself, and a context running CPM_KERNEL_AUTO uses the exact layout from then on. */
 int32_t cpm_resample_dev(cpm_ctx *ctx, uint64_t seed, uint32_t flags, void *d_counts);
 int32_t cpm_solve_ivp_async(cpm_ctx *ctx, uint64_t seed);
 /* procedural synthetic tables of SURVEY.md 8(d), generated on device (bench inputs):
@@ -153,8 +152,6 @@ int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
  * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
  * stream); returns the number written through *n_out */
 int32_t cpm_last_kernel_ms(cpm_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
-/* diagnostic (CPM_OPT_ABLATE 4): cycle sums of the fused sampler's segments since the last call */
-int32_t cpm_debug_cycles(cpm_ctx *ctx, uint64_t *out8);
 /* algorithmic HBM bytes of one hourly sampler launch */
 int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *ctx, int64_t *bytes_out);
 

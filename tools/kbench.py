@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=4096)
 ap.add_argument("--cpz", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--configs", default="car:0:0,zone:512:0,zone:0:0,fused:0:0")
+ap.add_argument("--configs", default="car:0:0,zone:512:0,zone:0:0,strided:0:0,grouped:0:0")
 args = ap.parse_args()
 
 Z, T, cpz = args.zones, 24, args.cpz
@@ -31,9 +31,7 @@ ref = None
 for cfg in args.configs.split(","):
     parts = cfg.split(":")
     kern, block, abl = parts[:3]
-    cpt = parts[3] if len(parts) > 3 else "3"
-    _lib.check(L.cpm_set_option(s._h, 4, int(cpt)))
-    s.set_kernel({"car": 1, "zone": 2, "fused": 3, "strided": 4, "grouped": 5}[kern])
+    s.set_kernel({"car": 1, "zone": 2, "strided": 4, "grouped": 5}[kern])
     _lib.check(L.cpm_set_option(s._h, 3, int(block)))
     _lib.check(L.cpm_set_option(s._h, 100, int(abl)))
     r = s.resample(0x5EEDCA125)
@@ -50,11 +48,4 @@ for cfg in args.configs.split(","):
         if ref is None:
             ref = r
         ok = "counts==first" if np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]) else "COUNTS DIFFER"
-    if int(abl) & 4:
-        buf = (ctypes.c_uint64 * 8)()
-        _lib.check(L.cpm_debug_cycles(s._h, ctypes.cast(buf, ctypes.c_void_p)))
-        tot = sum(buf) or 1
-        names = ["loop-top", "row wait + tree write", "prefetch issue + barrier", "philox + search", "compact + stores",
-                 "extra rounds + reductions", "closing barrier", "ticket"]
-        print("   segment shares:", ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, buf)))
     print(f"{cfg:16s} resample {dt*1e3:8.3f} ms   sampler launch avg {np.mean(ms)*1e3:8.1f} us (min {np.min(ms)*1e3:.1f} max {np.max(ms)*1e3:.1f}, n={len(ms)})  {C*T/dt:.3e} car-steps/s {ok}", flush=True)
