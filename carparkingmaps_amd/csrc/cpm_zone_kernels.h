@@ -1,13 +1,16 @@
-// cpm_zone_kernels.h -- CPM_KERNEL_ZONE_LDS: cars bucketed by zone, CDF row staged in LDS.
+// cpm_zone_kernels.h -- the zone sampler, and CPM_KERNEL_ZONE_LDS: the zone path on the exact
+// (packed) bucket layout.  cpm_zone3_kernels.h / cpm_zone5_kernels.h reuse the sampler on
+// fixed-stride buckets.
 //
 // The reference walks p_dest[origin,:,t] once per driving car (src/resampling.jl:34-45).  Here
 // the cars of one origin zone sit together, so the row is streamed from HBM exactly once per
 // hour (coalesced, 16 B per lane), kept in LDS, and every car of the zone searches it there.
 // Per hour t:
-//   k_zone_sample   one workgroup per origin zone: stage cdf[t][zone][:] in LDS; for each car of the
-//                   bucket: Philox -> Bernoulli (:11-22) -> categorical by binary search in LDS
-//                   (:26-49); writes dest|drive per slot, parking[t][zone] = bucket size,
-//                   driving[t][zone] = drivers (src/saveresults.jl:10-15) -- no histogram atomics.
+//   k_zone_sample2  one workgroup per origin zone: stage cdf[t][zone][:] in LDS (as a breadth-first
+//                   search tree); for each car of the bucket: Philox -> Bernoulli (:11-22) -> categorical
+//                   by tree walk in LDS (:26-49); writes dest|drive per slot, parking[t][zone] = bucket
+//                   size, driving[t][zone] = drivers (src/saveresults.jl:10-15) -- no histogram atomics.
+//                   (k_zone_sample: the first-generation form, sorted row + binary search, kept for A/B.)
 //   k_zone_hist     counting sort, pass 1: LDS-privatised histogram of the destinations of a
 //                   contiguous chunk of slots; one contiguous global atomic per (block, zone)
 //                   reserves the block's range in the zone's next bucket (ticket).
