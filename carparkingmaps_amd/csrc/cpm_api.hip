@@ -89,6 +89,11 @@ struct cpm_ctx {
     long long *h_status = nullptr;      // pinned
     hipEvent_t status_ev = nullptr;
     bool status_pending = false;
+    // An IVP enqueued on the fixed-stride layout writes the new state beside the old one; it is committed (or
+    // repeated on the exact layout) by finish_ivp() before anything reads or replaces the state.
+    bool ivp_pending = false;
+    uint64_t ivp_seed = 0;
+    long long *h_ivp_status = nullptr;  // pinned
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
@@ -237,10 +242,16 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
     return CPM_OK;
 }
 
+int32_t finish_ivp(cpm_ctx *c);
+
 int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_counts)
 {
     if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "resample: p_drive / p_dest not set");
     if (!c->have_state) return fail(CPM_ERR_STATE, "resample: no car state (cpm_init_states / cpm_set_state)");
+    {
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
     if (travel && !c->have_dm) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
@@ -292,19 +303,12 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     return launch_histogram(c, d_counts);
 }
 
-int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
+int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
 {
-    if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "solve_ivp: p_drive / p_dest not set");
-    if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
-    c->zw5.base.buckets0_valid = false;
-    if (c->n == 0) return CPM_OK;
     if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::zone_path_fits(c->Zp)) {
-        int32_t rc = cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                        static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr,
-                                        c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
-        return rc;
+        return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr,
+                                  c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
     }
     // src/solveinitialvalueproblem.jl:8 : t = 1:(T-1), state update unconditional (:53)
     for (int t = 0; t < c->T - 1; ++t) {
@@ -313,6 +317,50 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
         std::swap(c->d_zone0, c->d_ztmp);  // flag bit is masked off by every reader
     }
     return CPM_OK;
+}
+
+// Commit (or repeat on the exact layout) an IVP that was enqueued on the fixed-stride layout.  Called before
+// anything reads or replaces the car state.  Blocks until the IVP has drained.
+int32_t finish_ivp(cpm_ctx *c)
+{
+    if (!c->ivp_pending) return CPM_OK;
+    c->ivp_pending = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*c->h_ivp_status == 0) {
+        std::swap(c->d_zone0, c->d_ztmp);
+        HIP_TRY(cpm::zone5_commit_ivp(c->zw5, c->stream));
+        return CPM_OK;
+    }
+    c->grouped_overflowed = true;  // a bucket outgrew its region: d_zone0 is untouched, run the IVP again, exactly
+    return ivp_exact(c, c->ivp_seed);
+}
+
+int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
+{
+    if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "solve_ivp: p_drive / p_dest not set");
+    if (!c->have_state) return fail(CPM_ERR_STATE, "solve_ivp: no car state");
+    int32_t rc = finish_ivp(c);
+    if (rc != CPM_OK) return rc;
+    if (c->n == 0) return CPM_OK;
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z))) {
+        // the current state's buckets may be cached (zw5); everything else is stale once the IVP is committed
+        c->zw.buckets0_valid = false;
+        c->zw3.buckets0_valid = false;
+        HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
+        rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                 static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
+                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp);
+        if (rc != CPM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost,
+                               c->stream));
+        c->ivp_pending = true;
+        c->ivp_seed = seed;
+        return CPM_OK;
+    }
+    c->zw.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
+    c->zw5.base.buckets0_valid = false;
+    return ivp_exact(c, seed);
 }
 
 }  // namespace
@@ -371,6 +419,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(long long));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming);
     if (e == hipSuccess) *c->h_status = 0;
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_ivp_status), sizeof(long long));
     if (e != hipSuccess) {
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -398,6 +447,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     c->zw3.release();
     c->zw5.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_ivp_status) (void)hipHostFree(c->h_ivp_status);
     if (c->status_ev) (void)hipEventDestroy(c->status_ev);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -436,6 +486,10 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
 int32_t cpm_set_stream(cpm_ctx *c, void *hip_stream)
 {
     CTX_TRY(c);
+    {
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     return CPM_OK;
@@ -587,6 +641,10 @@ int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
 int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int64_t car_begin, int64_t car_count)
 {
     CTX_TRY(c);
+    if (c->ivp_pending) {  // the state is being replaced: the pending IVP's result is moot
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->ivp_pending = false;
+    }
     if (C_total < 0 || cars_per_zone < 1 || car_begin < 0 || car_count < 0 || car_begin + car_count > C_total)
         return fail(CPM_ERR_ARG, "init_states: bad car range [%lld, +%lld) of %lld", (long long)car_begin,
                     (long long)car_count, (long long)C_total);
@@ -614,6 +672,10 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
 {
     CTX_TRY(c);
     if (!c->have_state) return fail(CPM_ERR_STATE, "set_state: cpm_init_states first (defines the car range)");
+    if (c->ivp_pending) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->ivp_pending = false;
+    }
     c->zw.buckets0_valid = false;
     c->zw3.buckets0_valid = false;
     c->zw5.base.buckets0_valid = false;
@@ -638,6 +700,10 @@ int32_t cpm_get_state(cpm_ctx *c, int64_t *zones_out)
 {
     CTX_TRY(c);
     if (!c->have_state) return fail(CPM_ERR_STATE, "get_state: no car state");
+    {
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (c->n == 0) return CPM_OK;
     if (!zones_out) return fail(CPM_ERR_ARG, "null zones_out");
     int64_t *d_z = nullptr;
@@ -661,6 +727,8 @@ int32_t cpm_solve_ivp(cpm_ctx *c, uint64_t seed, int64_t *initial_state_out)
 {
     CTX_TRY(c);
     int32_t rc = ivp_enqueue(c, seed);
+    if (rc != CPM_OK) return rc;
+    rc = finish_ivp(c);
     if (rc != CPM_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (initial_state_out) return cpm_get_state(c, initial_state_out);

@@ -312,6 +312,7 @@ struct Zone5Work {
     uint2 *D = nullptr;          // [Z*cap]
     uint32_t *offz = nullptr;    // [Z][kGroups+1]
     uint32_t gmagic = 0;
+    const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;  // final buckets of the last IVP (see zone5_resample)
     int zpg = 0, zps = 0;
     int64_t n = 0;
     int Z = 0, T = 0;
@@ -379,11 +380,26 @@ inline void zone5_launch(const Zone5Args &a, size_t lds, hipStream_t stream)
     else zone5_launch_np<TRAVEL, 16>(a, lds, stream);
 }
 
-// The T-hour resample from the state in d_zone0 (left unchanged); status word as in zone3_resample.
+// car-indexed state from fixed-stride buckets
+__global__ void k_zone5_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt, uint32_t cap,
+                                 uint32_t *__restrict__ zone0)
+{
+    const uint32_t z = blockIdx.x;
+    const uint32_t n = min(cnt[z], cap);
+    for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) zone0[ids[static_cast<size_t>(z) * cap + s]] = z;
+}
+
+// ivp == false: the T-hour resample from the state in d_zone0 (left unchanged); status word as in zone3_resample.
+// ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps 0..T-2, every
+//               transition applied.  d_zone0 is NOT modified: the new car-indexed state goes to d_zone0_out and the
+//               final buckets are remembered in w5.ivp_ids / w5.ivp_cnt.  The caller inspects the status word when
+//               the stream has drained and then either commits (zone5_commit_ivp + pointer swap) or repeats the IVP
+//               on the exact layout from the untouched d_zone0.
 template <typename F1, typename F2>
 int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
                        int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
-                       const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err)
+                       const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err,
+                       bool ivp = false, uint32_t *d_zone0_out = nullptr)
 {
     auto hip_fail = [&](hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -433,11 +449,12 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
     a.car_begin = car_begin;
     a.seed = seed;
     const uint32_t *ids = w.ids0, *cnt = w.cnt0;
-    for (int t = 0; t < T; ++t) {
+    const int hours = ivp ? T - 1 : T;
+    for (int t = 0; t < hours; ++t) {
         const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
         const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
-        const uint32_t step = static_cast<uint32_t>(T - 1 + t);
-        if (t + 1 == T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83): counts only
+        const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
+        if (!ivp && t + 1 == T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83): counts only
             prof_begin(t);
             launch_zone_sample(w.sampler, stream, travel, ids, cnt, pd, cdf, Z, Zp, car_begin, step, seed,
                                parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum, 0,
@@ -467,7 +484,26 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
     }
+    if (ivp) {
+        hipLaunchKernelGGL(k_zone5_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, w.cap, d_zone0_out);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
+        w5.ivp_ids = ids;
+        w5.ivp_cnt = cnt;
+        w.buckets0_valid = false;  // until zone5_commit_ivp
+    }
     return CPM_OK;
+}
+
+// After a verified IVP: its final buckets become the cached bucketing of the (new) current state.
+inline hipError_t zone5_commit_ivp(Zone5Work &w5, hipStream_t stream)
+{
+    Zone3Work &w = w5.base;
+    hipError_t e = hipSuccess;
+    if (w5.ivp_ids != w.ids0)
+        e = hipMemcpyAsync(w.ids0, w5.ivp_ids, sizeof(uint32_t) * static_cast<size_t>(w.Z) * w.cap, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.cnt0, w5.ivp_cnt, sizeof(uint32_t) * w.Z, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) w.buckets0_valid = true;
+    return e;
 }
 
 }  // namespace cpm
