@@ -57,8 +57,10 @@ struct Zone5Args {
     uint64_t seed;
 };
 
+// Second launch-bounds argument = waves per SIMD: 8 (four 512-thread workgroups per CU).  Without it the
+// kernel took 91 SGPRs, which the hardware admits at only 7 waves per SIMD, i.e. three workgroups per CU.
 template <bool TRAVEL, int BLOCK, int NP, int CPT>
-__global__ __launch_bounds__(BLOCK) void k_zone5_sample(Zone5Args a)
+__global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_sample(Zone5Args a)
 {
     extern __shared__ double row[];  // 2^H doubles: the zone's CDF row as a search tree
     __shared__ uint32_t s_ndrive, s_nstay;
@@ -197,39 +199,36 @@ __global__ __launch_bounds__(BLOCK) void k_zone5_sample(Zone5Args a)
         if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
     }
     __syncthreads();  // group counts, stayer count final
-    // group offsets inside this zone's region of D: exclusive scan of the 32 group counts (one wave)
-    if (tid < 64) {
-        const uint32_t c = (tid < kGroups) ? gb[tid] : 0u;
-        uint32_t incl = c;
-        for (int o = 1; o < kGroups; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, 64);
-            if (tid >= o) incl += v;
-        }
-        const uint32_t total = __shfl(incl, kGroups - 1, 64);
-        if (tid < kGroups) gb[tid] = incl - c;
-        if (tid <= kGroups) a.offz[static_cast<size_t>(z) * (kGroups + 1) + tid] = (tid < kGroups) ? incl - c : total;
+    // Group offsets inside this zone's region of D = exclusive scan of the 32 group counts.  Every wave
+    // scans them for itself (32 LDS reads + 5 shuffles) and keeps offset g in lane g, so no second
+    // barrier is needed before the pairs are written; wave 0 publishes the offsets for k_zone5_place.
+    const uint32_t gcount = gb[lane & (kGroups - 1)];
+    uint32_t incl = gcount;
+    for (int o = 1; o < kGroups; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((lane & (kGroups - 1)) >= o) incl += v;
     }
+    const uint32_t excl = incl - gcount;  // lanes g and g + 32 both hold the offset of group g
+    const uint32_t gtotal = __shfl(incl, kGroups - 1, 64);
+    if (tid <= kGroups) a.offz[static_cast<size_t>(z) * (kGroups + 1) + tid] = (tid < kGroups) ? excl : gtotal;
     if (tid == 0) {
         a.driving_t[z] = s_ndrive;
         a.cnt_next[z] = s_nstay;  // k_zone5_place adds the arrivals
         if (TRAVEL && s_tt) atomicAdd(a.tt_sum, s_tt);
     }
-    __syncthreads();
-    // drivers -> their group's list
+    // drivers -> the run of their destination group
 #pragma unroll
-    for (int c = 0; c < CPT; ++c)
-        if (rec[c] & kDriveBit) {
-            const uint32_t dest = rec[c] & kDest14, g = (dest * a.gmagic) >> 24;
-            const uint32_t p = gb[g] + ((rec[c] & kZoneMask) >> kRankShift);
-            a.D[static_cast<size_t>(b) + p] = make_uint2(id[c], dest);
-        }
-    for (uint32_t q = CPT * BLOCK + tid; q < n; q += BLOCK) {
-        const uint32_t r = a.rec[b + q];
-        if (r & kDriveBit) {
-            const uint32_t dest = r & kDest14, g = (dest * a.gmagic) >> 24;
-            const uint32_t p = gb[g] + ((r & kZoneMask) >> kRankShift);
-            a.D[static_cast<size_t>(b) + p] = make_uint2(a.ids[b + q], dest);
-        }
+    for (int c = 0; c < CPT; ++c) {
+        const uint32_t dest = rec[c] & kDest14, g = (dest * a.gmagic) >> 24;
+        const uint32_t base = __shfl(excl, static_cast<int>(g), 64);
+        if (rec[c] & kDriveBit) a.D[static_cast<size_t>(b) + base + ((rec[c] & kZoneMask) >> kRankShift)] = make_uint2(id[c], dest);
+    }
+    for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // wave-uniform trips (the shuffle needs every lane)
+        const uint32_t q = q0 + tid;
+        const uint32_t r = (q < n) ? a.rec[b + q] : 0u;
+        const uint32_t dest = r & kDest14, g = (dest * a.gmagic) >> 24;
+        const uint32_t base = __shfl(excl, static_cast<int>(g), 64);
+        if (r & kDriveBit) a.D[static_cast<size_t>(b) + base + ((r & kZoneMask) >> kRankShift)] = make_uint2(a.ids[b + q], dest);
     }
 }
 
