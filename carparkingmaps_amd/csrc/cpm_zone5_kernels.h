@@ -87,6 +87,9 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
     uint32_t id[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) id[c] = a.ids[b + min(static_cast<uint32_t>(tid + c * BLOCK), n - 1)];
+    // the id of the first overflow round (buckets of CPT*BLOCK+1 .. (CPT+1)*BLOCK cars are common) rides along:
+    // loaded here it costs nothing, loaded inside the overflow loop it is an exposed HBM round trip
+    const uint32_t id_x = a.ids[b + min(static_cast<uint32_t>(tid + CPT * BLOCK), n - 1)];
     double2 pc[NP];
     const double2 *src = reinterpret_cast<const double2 *>(a.cdf_t + static_cast<size_t>(z) * Zp);
 #pragma unroll
@@ -169,10 +172,12 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
             }
         }
     }
+    uint32_t rec_x = 0;  // record of the first overflow round, kept in a register across the barrier
     for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
         const uint32_t q = q0 + tid;
         const bool valid = q < n;
-        const uint32_t idx = valid ? a.ids[b + q] : 0u;
+        const bool first = q0 == CPT * BLOCK;
+        const uint32_t idx = first ? id_x : (valid ? a.ids[b + q] : 0u);
         const uint64_t car = static_cast<uint64_t>(a.car_begin) + idx;
         long long kb;
         double uc;
@@ -190,7 +195,8 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
             ++nd;
         }
         const uint32_t r = place(idx, valid, drive, dest);
-        if (valid) a.rec[b + q] = r;  // needed again after the ticket
+        if (first) rec_x = r;
+        else if (valid) a.rec[b + q] = r;  // needed again after the barrier
     }
     for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
     if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
@@ -225,10 +231,12 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
     }
     for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // wave-uniform trips (the shuffle needs every lane)
         const uint32_t q = q0 + tid;
-        const uint32_t r = (q < n) ? a.rec[b + q] : 0u;
+        const bool first = q0 == CPT * BLOCK;
+        const uint32_t r = first ? rec_x : ((q < n) ? a.rec[b + q] : 0u);
         const uint32_t dest = r & kDest14, g = (dest * a.gmagic) >> 24;
         const uint32_t base = __shfl(excl, static_cast<int>(g), 64);
-        if (r & kDriveBit) a.D[static_cast<size_t>(b) + base + ((r & kZoneMask) >> kRankShift)] = make_uint2(a.ids[b + q], dest);
+        if (r & kDriveBit)
+            a.D[static_cast<size_t>(b) + base + ((r & kZoneMask) >> kRankShift)] = make_uint2(first ? id_x : a.ids[b + q], dest);
     }
 }
 

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample2(
     uint32_t id[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) id[c] = ids[b + min(static_cast<uint32_t>(tid + c * BLOCK), n - 1)];
+    // the id of the first overflow round rides along (inside the overflow loop it would be an exposed HBM round trip)
+    const uint32_t id_x = ids[b + min(static_cast<uint32_t>(tid + CPT * BLOCK), n - 1)];
     double2 pc[NP];
     const double2 *src = reinterpret_cast<const double2 *>(cdf_t + static_cast<size_t>(z) * Zp);
 #pragma unroll
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample2(
         }
     }
     for (uint32_t s = b + CPT * BLOCK + tid; s < e; s += BLOCK) {  // buckets larger than CPT*BLOCK cars
-        const uint32_t idx = ids[s];
+        const uint32_t idx = (s < b + (CPT + 1) * BLOCK) ? id_x : ids[s];
         const uint64_t car = static_cast<uint64_t>(car_begin) + idx;
         long long kb;
         double uc;
