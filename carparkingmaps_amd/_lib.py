@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcpm_hip.so")
+LIB_PATH = os.environ.get("CPM_LIB_PATH") or os.path.join(CSRC, "libcpm_hip.so")  # override: diagnostic twin, tools only
 
 # every symbol include/cpm.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -18,12 +18,14 @@ SYMBOLS = [
     "cpm_build_p_drive", "cpm_build_p_dest", "cpm_get_p_drive", "cpm_get_cdf_row", "cpm_init_states",
     "cpm_set_state", "cpm_get_state", "cpm_solve_ivp", "cpm_resample", "cpm_resample_dev",
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
+    "cpm_debug_categorical",
 ]
 
 CPM_FLAG_TRAVEL = 1
 CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
 CPM_KERNEL_ZONE_STRIDED, CPM_KERNEL_ZONE_GROUPED = 4, 5
 CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
+CPM_OPT_PLACE_SHAPE, CPM_OPT_GROUPED_GEN, CPM_OPT_SAMPLER_SHAPE = 4, 5, 6
 
 _lib = None
 
@@ -91,6 +93,7 @@ def load():
     L.cpm_synth_tables.argtypes = [vp, u64]
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
+    L.cpm_debug_categorical.argtypes = [vp, i64, i64, i64, vp, vp, C.POINTER(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("cpm_last_error",):

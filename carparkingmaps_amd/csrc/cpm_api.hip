@@ -65,6 +65,9 @@ struct cpm_ctx {
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
     double *d_cdf = nullptr;     // [T][Z][Zp]
+    uint32_t *d_hi = nullptr;    // [T][Z][Zq] high words of the CDF (cpm_zone6_kernels.h)
+    double *d_last = nullptr;    // [T][Z] row totals
+    int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
     double *d_dist = nullptr;    // [Z][Z]
     bool have_pdrive = false, have_cdf = false, have_dm = false;
@@ -156,6 +159,15 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
     int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)",
                                 CPM_ERR_TABLE);
     if (rc != CPM_OK) return rc;
+    if (cpm::zone6_row_fits(static_cast<int>(c->Z))) {  // the high-word table of the grouped zone path
+        const int64_t rows = c->T * c->Z;
+        if (!c->d_hi) HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * static_cast<size_t>(rows) * c->Zq));
+        if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
+        const unsigned gy = static_cast<unsigned>(std::min<int64_t>(rows, 32768)), gz = static_cast<unsigned>((rows + gy - 1) / gy);
+        hipLaunchKernelGGL(cpm::k_build_hi32, dim3(nblk(c->Zq, 256), gy, gz), dim3(256), 0, c->stream, c->d_cdf, c->d_hi, c->d_last,
+                           static_cast<int>(c->Z), c->Zp, c->Zq, rows);
+        HIP_TRY(hipGetLastError());
+    }
     c->have_cdf = true;
     c->zw.tables_dirty = true;
     return CPM_OK;
@@ -268,7 +280,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                          static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
                                          d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                         g_last_error);
+                                         g_last_error, false, nullptr, c->d_hi, c->d_last, c->Zq);
         if (rc == CPM_OK && c->h_status && !c->status_pending) {
             if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                 hipEventRecord(c->status_ev, c->stream) == hipSuccess)
@@ -349,7 +361,7 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
         HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
         rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
-                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp);
+                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq);
         if (rc != CPM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost,
                                c->stream));
@@ -408,6 +420,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     c->Z = Z;
     c->T = T;
     c->Zp = static_cast<int>((Z + 15) / 16 * 16);
+    c->Zq = static_cast<int>((Z + 31) / 32 * 32);
     c->device = device_id;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->cu_count = p.multiProcessorCount;
@@ -436,6 +449,8 @@ int32_t cpm_destroy(cpm_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_pdrive);
     dfree(c->d_cdf);
+    dfree(c->d_hi);
+    dfree(c->d_last);
     dfree(c->d_dm);
     dfree(c->d_dist);
     dfree(c->d_zone0);
@@ -475,8 +490,22 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->zw.tree = (value == 0);
         if (value) c->zw.block = static_cast<int>(value);
         return CPM_OK;
+    case CPM_OPT_PLACE_SHAPE:
+        if (value != 81 && value != 82 && value != 161 && value != 162) return fail(CPM_ERR_ARG, "place shape %lld", (long long)value);
+        c->zw5.bpg = static_cast<int>(value / 10);
+        c->zw5.deep = static_cast<int>(value % 10);
+        return CPM_OK;
+    case CPM_OPT_GROUPED_GEN:
+        if (value != 5 && value != 6) return fail(CPM_ERR_ARG, "grouped generation %lld", (long long)value);
+        c->zw5.v6 = (value == 6);
+        return CPM_OK;
+    case CPM_OPT_SAMPLER_SHAPE:
+        if (value < 0 || value > 2) return fail(CPM_ERR_ARG, "sampler shape %lld", (long long)value);
+        c->zw5.shape6 = static_cast<int>(value);
+        return CPM_OK;
     case CPM_OPT_ABLATE:
         c->zw.ablate = static_cast<int>(value);
+        c->zw5.base.sampler.ablate = static_cast<int>(value);
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown option %d", option);
@@ -814,7 +843,51 @@ int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
 {
     if (!c || !bytes_out) return fail(CPM_ERR_ARG, "null argument");
     // B/T = Z*Z*8 (CDF slab) + Z*8 (p_drive) + C_g*8 (4 B zone in + 4 B out) + 2*Z*8 (counts)
-    *bytes_out = c->Z * c->Z * 8 + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
+    // The second-generation grouped path streams the 4-byte high-word rows (Zq per row) instead of the f64 rows:
+    // its true element size is substituted, as 8(d) prescribes for a variant with a different element size.
+    const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zw5.v6 && c->d_hi &&
+                         cpm::zone6_path_fits(c->Zp, c->n, static_cast<int>(c->Z));
+    const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(c->Zq) * 4 + c->Z * 8 : c->Z * c->Z * 8;
+    *bytes_out = rows + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
+    return CPM_OK;
+}
+
+int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_t n, const uint64_t *k53, int64_t *dest_out,
+                              int32_t *n_exact_out)
+{
+    CTX_TRY(c);
+    if (!c->have_cdf || !c->d_hi) return fail(CPM_ERR_STATE, "debug_categorical: p_dest not set (or rows too long for the high-word table)");
+    if (origin1 < 1 || origin1 > c->Z || hour1 < 1 || hour1 > c->T) return fail(CPM_ERR_ARG, "row index out of range");
+    if (n < 0 || (n > 0 && (!k53 || !dest_out))) return fail(CPM_ERR_ARG, "bad draw list");
+    if (n_exact_out) *n_exact_out = 0;
+    if (n == 0) return CPM_OK;
+    const size_t row = static_cast<size_t>(hour1 - 1) * c->Z + (origin1 - 1);
+    uint64_t *d_k = nullptr;
+    int64_t *d_o = nullptr;
+    int *d_n = nullptr;
+    hipError_t e = hipMalloc(&d_k, sizeof(uint64_t) * n);
+    if (e == hipSuccess) e = hipMalloc(&d_o, sizeof(int64_t) * n);
+    if (e == hipSuccess) e = hipMalloc(&d_n, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_k, k53, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int H = cpm::tree_height(static_cast<int>(c->Z));
+        const size_t lds = sizeof(uint32_t) * (size_t(1) << H);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_zone6_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(cpm::k_zone6_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * c->Zq, c->d_last + row,
+                           c->d_cdf + row * c->Zp, static_cast<int>(c->Z), c->Zq, H, n, d_k, d_o, d_n);
+        e = hipGetLastError();
+    }
+    int h_n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(dest_out, d_o, sizeof(int64_t) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_n, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d_k);
+    dfree(d_o);
+    dfree(d_n);
+    if (e != hipSuccess) return fail(CPM_ERR_HIP, "debug_categorical: %s", hipGetErrorString(e));
+    if (n_exact_out) *n_exact_out = h_n;
     return CPM_OK;
 }
 

@@ -32,6 +32,7 @@
 #include "cpm_kernels.h"
 #include "cpm_zone_kernels.h"
 #include "cpm_zone3_kernels.h"
+#include "cpm_zone6_kernels.h"
 
 namespace cpm {
 
@@ -240,12 +241,13 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
     }
 }
 
-// Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the kBlocksPerGroup
-// blocks of a group share blockIdx % 8 (one XCD, one L2; speed only, never correctness).  Block (g, j)
-// gathers the group-g runs of the origin zones [j*zps, (j+1)*zps); 16 lanes per run.
+// Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share
+// blockIdx % 8 (one XCD, one L2; speed only, never correctness).  Block (g, j) gathers the group-g runs of
+// the origin zones [j*zps, (j+1)*zps); 16 lanes per run, KDEEP pairs per lane held in registers.
 constexpr int kPlaceBlock = 1024;
 constexpr int kPlaceSeg = kPlaceBlock / 16;  // runs in flight per pass
 
+template <int KRUNS, int KDEEP>
 __global__ __launch_bounds__(kPlaceBlock) void k_zone5_place(const uint2 *__restrict__ D, const uint32_t *__restrict__ offz,
                                                              int zpg, int zps, int Z, uint32_t cap,
                                                              uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
@@ -260,14 +262,15 @@ __global__ __launch_bounds__(kPlaceBlock) void k_zone5_place(const uint2 *__rest
     const int sub = tid >> 4, l16 = tid & 15;
     for (int k = tid; k < kMaxZonesPerGroup; k += kPlaceBlock) bins[k] = 0;
     __syncthreads();
-    // Every thread owns the lane-l16 pair of kRuns runs (origin zones zs0 + sub + k * kPlaceSeg): descriptors
-    // and pairs are loaded once, all loads in flight together, and kept in registers across the ticket.
-    // Pairs beyond the 16th of a run (runs average ~16) are re-read in pass 2.
-    constexpr int kRuns = 8;  // zps <= kRuns * kPlaceSeg = 512 origin zones per block
-    uint32_t o0[kRuns], o1[kRuns];
-    uint2 v[kRuns];
+    // Every thread owns lane l16 of KRUNS runs (origin zones zs0 + sub + k * kPlaceSeg) and the pairs
+    // l16, l16 + 16, ... (KDEEP of them) of each: descriptors, then all pairs, are requested together and stay
+    // in registers across the ticket.  (With one pair per lane the second sixteen of a run -- runs average ~16
+    // at S4k -- were fetched inside the histogram loop, one exposed round trip per run: 20 us per launch.)
+    // Pairs beyond 16 * KDEEP of a run take the loops below and are re-read in pass 2.
+    uint32_t o0[KRUNS], o1[KRUNS];
+    uint2 v[KRUNS][KDEEP];
 #pragma unroll
-    for (int k = 0; k < kRuns; ++k) {
+    for (int k = 0; k < KRUNS; ++k) {
         const int zs = zs0 + sub + k * kPlaceSeg;
         const int zc = min(zs, zs1 - 1);
         o0[k] = offz[static_cast<size_t>(zc) * (kGroups + 1) + g];
@@ -275,17 +278,25 @@ __global__ __launch_bounds__(kPlaceBlock) void k_zone5_place(const uint2 *__rest
         if (zs >= zs1) o1[k] = o0[k];
     }
 #pragma unroll
-    for (int k = 0; k < kRuns; ++k) {
+    for (int k = 0; k < KRUNS; ++k) {
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
-        v[k] = make_uint2(0u, static_cast<uint32_t>(zg0));
-        if (o0[k] + l16 < o1[k]) v[k] = D[static_cast<size_t>(zc) * cap + o0[k] + l16];
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d) {
+            v[k][d] = make_uint2(0u, static_cast<uint32_t>(zg0));
+            if (o0[k] + l16 + 16 * d < o1[k]) v[k][d] = D[static_cast<size_t>(zc) * cap + o0[k] + l16 + 16 * d];
+        }
     }
     // pass 1: histogram of the destinations over the group's zones
 #pragma unroll
-    for (int k = 0; k < kRuns; ++k) {
+    for (int k = 0; k < KRUNS; ++k) {
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d)
+            if (o0[k] + l16 + 16 * d < o1[k]) atomicAdd(&bins[v[k][d].y - zg0], 1u);
+    }
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
-        if (o0[k] + l16 < o1[k]) atomicAdd(&bins[v[k].y - zg0], 1u);
-        for (uint32_t i = o0[k] + l16 + 16; i < o1[k]; i += 16) atomicAdd(&bins[D[static_cast<size_t>(zc) * cap + i].y - zg0], 1u);
+        for (uint32_t i = o0[k] + l16 + 16 * KDEEP; i < o1[k]; i += 16) atomicAdd(&bins[D[static_cast<size_t>(zc) * cap + i].y - zg0], 1u);
     }
     __syncthreads();
     if (tid < nzl) {  // ticket: this block's range inside each bucket of the group
@@ -300,18 +311,48 @@ __global__ __launch_bounds__(kPlaceBlock) void k_zone5_place(const uint2 *__rest
     __syncthreads();
     // pass 2: the ids move
 #pragma unroll
-    for (int k = 0; k < kRuns; ++k) {
+    for (int k = 0; k < KRUNS; ++k) {
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d)
+            if (o0[k] + l16 + 16 * d < o1[k]) {
+                const uint32_t p = atomicAdd(&bins[v[k][d].y - zg0], 1u);
+                if (p < cap) ids_next[static_cast<size_t>(v[k][d].y) * cap + p] = v[k][d].x;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
-        if (o0[k] + l16 < o1[k]) {
-            const uint32_t p = atomicAdd(&bins[v[k].y - zg0], 1u);
-            if (p < cap) ids_next[static_cast<size_t>(v[k].y) * cap + p] = v[k].x;
-        }
-        for (uint32_t i = o0[k] + l16 + 16; i < o1[k]; i += 16) {
+        for (uint32_t i = o0[k] + l16 + 16 * KDEEP; i < o1[k]; i += 16) {
             const uint2 w = D[static_cast<size_t>(zc) * cap + i];
             const uint32_t p = atomicAdd(&bins[w.y - zg0], 1u);
             if (p < cap) ids_next[static_cast<size_t>(w.y) * cap + p] = w.x;
         }
     }
+}
+
+// Launch with bpg blocks per group (8 or 16): zps origin zones per block must fit KRUNS * kPlaceSeg.
+inline void zone5_launch_place(hipStream_t stream, int bpg, int deep, const uint2 *D, const uint32_t *offz, int zpg, int Z, uint32_t cap,
+                               uint32_t *cnt_next, uint32_t *ids_next, unsigned long long *status)
+{
+    const int zps = (Z + bpg - 1) / bpg;
+    const dim3 grid(kGroups * bpg), block(kPlaceBlock);
+    if (zps <= 4 * kPlaceSeg) {
+        if (deep >= 2) hipLaunchKernelGGL((k_zone5_place<4, 2>), grid, block, 0, stream, D, offz, zpg, zps, Z, cap, cnt_next, ids_next, status);
+        else hipLaunchKernelGGL((k_zone5_place<4, 1>), grid, block, 0, stream, D, offz, zpg, zps, Z, cap, cnt_next, ids_next, status);
+    } else {
+        if (deep >= 2) hipLaunchKernelGGL((k_zone5_place<8, 2>), grid, block, 0, stream, D, offz, zpg, zps, Z, cap, cnt_next, ids_next, status);
+        else hipLaunchKernelGGL((k_zone5_place<8, 1>), grid, block, 0, stream, D, offz, zpg, zps, Z, cap, cnt_next, ids_next, status);
+    }
+}
+
+// run capacity of the second-generation layout: a quarter of a bucket region (= the mean bucket size), >= 64, whole 128-B lines
+inline uint32_t zone6_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
+// packed driver = id | (dest - group start) << idbits
+inline uint32_t zone6_idbits(int zpg)
+{
+    int gbits = 1;
+    while ((1 << gbits) < zpg) ++gbits;
+    return static_cast<uint32_t>(32 - gbits);
 }
 
 struct Zone5Work {
@@ -320,7 +361,14 @@ struct Zone5Work {
     uint32_t *offz = nullptr;    // [Z][kGroups+1]
     uint32_t gmagic = 0;
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;  // final buckets of the last IVP (see zone5_resample)
-    int zpg = 0, zps = 0;
+    int zpg = 0;
+    int bpg = kBlocksPerGroup, deep = 2;  // k_zone5_place shape (CPM_OPT_PLACE_SHAPE, A/B runs)
+    // second generation (cpm_zone6_kernels.h): high-word rows, fixed-size runs
+    bool v6 = true;              // CPM_OPT_GROUPED_GEN: 6 (default) or 5
+    int shape6 = 0;              // sampler shape, see zone6_launch
+    uint32_t *Dq = nullptr;      // [Z][kGroups][scap] packed drivers
+    uint32_t *cntg = nullptr;    // [Z][kGroups] run lengths
+    uint32_t scap = 0, idbits = 0;
     int64_t n = 0;
     int Z = 0, T = 0;
 
@@ -329,8 +377,12 @@ struct Zone5Work {
         base.release();
         if (D) (void)hipFree(D);
         if (offz) (void)hipFree(offz);
+        if (Dq) (void)hipFree(Dq);
+        if (cntg) (void)hipFree(cntg);
         D = nullptr;
         offz = nullptr;
+        Dq = nullptr;
+        cntg = nullptr;
         n = 0;
     }
 
@@ -341,16 +393,23 @@ struct Zone5Work {
         if (n_ == n && Z_ == Z && T_ == T && D) return hipSuccess;
         if (D) (void)hipFree(D);
         if (offz) (void)hipFree(offz);
+        if (Dq) (void)hipFree(Dq);
+        if (cntg) (void)hipFree(cntg);
         D = nullptr;
         offz = nullptr;
+        Dq = nullptr;
+        cntg = nullptr;
         n = n_;
         Z = Z_;
         T = T_;
         zpg = (Z + kGroups - 1) / kGroups;
-        zps = (Z + kBlocksPerGroup - 1) / kBlocksPerGroup;
         gmagic = (1u << 24) / static_cast<uint32_t>(zpg) + 1u;  // exact for dest < 2^14 (2^24 / zpg >= 2^15)
         e = hipMalloc(&D, sizeof(uint2) * static_cast<size_t>(Z) * base.cap);
         if (e == hipSuccess) e = hipMalloc(&offz, sizeof(uint32_t) * static_cast<size_t>(Z) * (kGroups + 1));
+        scap = zone6_scap(base.cap);
+        idbits = zone6_idbits(zpg);
+        if (e == hipSuccess) e = hipMalloc(&Dq, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups * scap);
+        if (e == hipSuccess) e = hipMalloc(&cntg, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups);
         if (e != hipSuccess) release();
         return e;
     }
@@ -362,6 +421,16 @@ inline bool zone5_path_fits(int Zp, int64_t n, int Z)
     return zone3_path_fits(Zp, n, Z) && Z <= (1 << kRankShift) && (Z + kGroups - 1) / kGroups <= kMaxZonesPerGroup &&
            (Z + kBlocksPerGroup - 1) / kBlocksPerGroup <= 8 * kPlaceSeg &&
            n < (int64_t(1) << 30) && std::max<int64_t>(4 * mean, 1024) + 64 <= (int64_t(1) << (31 - kRankShift));  // rank field
+}
+
+// second generation: also the packed id field and the run array (Z x 32 x scap x 4 B <= 16 GiB)
+inline bool zone6_path_fits(int Zp, int64_t n, int Z)
+{
+    if (!zone5_path_fits(Zp, n, Z) || !zone6_row_fits(Z)) return false;
+    const int64_t mean = (n + Z - 1) / Z;
+    const uint32_t cap = static_cast<uint32_t>((std::max<int64_t>(4 * mean, 1024) + 63) / 64 * 64);
+    const int zpg = (Z + kGroups - 1) / kGroups;
+    return n <= (int64_t(1) << zone6_idbits(zpg)) && static_cast<int64_t>(Z) * kGroups * zone6_scap(cap) * 4 <= (int64_t(16) << 30);
 }
 
 template <bool TRAVEL, int NP>
@@ -406,12 +475,14 @@ template <typename F1, typename F2>
 int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
                        int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
                        const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err,
-                       bool ivp = false, uint32_t *d_zone0_out = nullptr)
+                       bool ivp = false, uint32_t *d_zone0_out = nullptr, const uint32_t *d_hi = nullptr,
+                       const double *d_last = nullptr, int Zq = 0)
 {
     auto hip_fail = [&](hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
     };
+    const bool v6 = w5.v6 && d_hi && d_last && zone6_path_fits(Zp, n, Z);
     hipError_t e = w5.ensure(n, Z, T, cu_count);
     if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
     Zone3Work &w = w5.base;
@@ -461,7 +532,52 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
         const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
         const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
         const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
-        if (!ivp && t + 1 == T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83): counts only
+        if (v6) {
+            const bool last_hour = !ivp && t + 1 == T;  // sampled, never applied (src/resampling.jl:81-83): counts only
+            uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * Z;
+            uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
+            Zone6Args b;
+            b.ids = ids;
+            b.cnt = cnt;
+            b.hi_t = d_hi + static_cast<size_t>(t) * Z * Zq;
+            b.last_t = d_last + static_cast<size_t>(t) * Z;
+            b.pdrive_t = pd;
+            b.cdf_t = cdf;
+            b.dm = d_dm;
+            b.ids_next = ids_next;
+            b.cnt_next = cnt_next;
+            b.D = w5.Dq;
+            b.cntg = w5.cntg;
+            b.rec_out = w.dest;
+            b.parking_t = parking + static_cast<size_t>(t) * Z;
+            b.driving_t = driving + static_cast<size_t>(t) * Z;
+            b.tt_sum = tt_sum;
+            b.status = status;
+            b.Z = Z;
+            b.Zp = Zp;
+            b.Zq = Zq;
+            b.H = H;
+            b.T = T;
+            b.t = t;
+            b.zpg = w5.zpg;
+            b.cap = w.cap;
+            b.scap = w5.scap;
+            b.idbits = w5.idbits;
+            b.step = step;
+            b.gmagic = w5.gmagic;
+            b.car_begin = car_begin;
+            b.seed = seed;
+            b.abl = w.sampler.ablate;
+            prof_begin(t);
+            if (last_hour) zone6_launch<false>(b, travel, w5.shape6, cu_count, stream);
+            else zone6_launch<true>(b, travel, w5.shape6, cu_count, stream);
+            prof_end(t);
+            if (!last_hour) {
+                zone6_launch_place(stream, w5.bpg, w5.Dq, w5.cntg, w5.zpg, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
+                ids = ids_next;
+                cnt = cnt_next;
+            }
+        } else if (!ivp && t + 1 == T) {  // hour T's transition is sampled but never applied (src/resampling.jl:81-83): counts only
             prof_begin(t);
             launch_zone_sample(w.sampler, stream, travel, ids, cnt, pd, cdf, Z, Zp, car_begin, step, seed,
                                parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum, 0,
@@ -484,8 +600,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             if (travel) zone5_launch<true>(a, lds_tree, stream);
             else zone5_launch<false>(a, lds_tree, stream);
             prof_end(t);
-            hipLaunchKernelGGL(k_zone5_place, dim3(kGroups * kBlocksPerGroup), dim3(kPlaceBlock), 0, stream, w5.D, w5.offz, w5.zpg,
-                               w5.zps, Z, w.cap, cnt_next, ids_next, status);
+            zone5_launch_place(stream, w5.bpg, w5.deep, w5.D, w5.offz, w5.zpg, Z, w.cap, cnt_next, ids_next, status);
             ids = ids_next;
             cnt = cnt_next;
         }

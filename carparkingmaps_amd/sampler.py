@@ -52,6 +52,10 @@ class Sampler:
     def set_kernel(self, kernel):
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
 
+    def set_option(self, option, value):
+        """Raw cpm_set_option (tuning / A-B options of include/cpm.h)."""
+        _lib.check(self._L.cpm_set_option(self._h, int(option), int(value)))
+
     def set_profile(self, on=True, stride=1):
         """hipEvents around every `stride`-th hourly sampler launch (0 / False: off)."""
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(stride) if on else 0))
@@ -153,6 +157,16 @@ class Sampler:
         n = C.c_int32(0)
         _lib.check(self._L.cpm_last_kernel_ms(self._h, C.cast(buf, C.c_void_p), 8192, C.byref(n)))
         return [float(buf[i]) for i in range(n.value)]
+
+    def debug_categorical(self, origin, hour, k53):
+        """Diagnostic: destinations (1-based; 0 = all-zero row) the grouped zone sampler draws from row
+        (origin, hour) for the 53-bit uniforms k53 (u = k * 2^-53); also the number of exact-row fallbacks."""
+        k = np.ascontiguousarray(k53, dtype=np.uint64)
+        out = np.zeros(k.shape[0], dtype=np.int64)
+        n_exact = C.c_int32(0)
+        _lib.check(self._L.cpm_debug_categorical(self._h, int(origin), int(hour), int(k.shape[0]), _vp(k), _vp(out),
+                                                 C.byref(n_exact)))
+        return out, int(n_exact.value)
 
     def algorithmic_bytes_per_hour(self):
         b = C.c_int64(0)

@@ -68,6 +68,9 @@ extern "C" {
 #define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
                                    pair costs ~10 us of stream bubbles, so sample); 0: off */
 #define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
+#define CPM_OPT_PLACE_SHAPE 4   /* tuning: grouped path, blocks per destination group * 10 + pairs per lane (82, 81, 162, 161) */
+#define CPM_OPT_GROUPED_GEN 5   /* A/B: 6 (default) = high-word rows + fixed-size runs, 5 = first generation (f64 rows) */
+#define CPM_OPT_SAMPLER_SHAPE 6 /* tuning: generation-6 sampler, 0 = 512 threads x 2 cars, 1 = 256 threads x 4 cars */
 #define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;
@@ -152,8 +155,17 @@ int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
  * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
  * stream); returns the number written through *n_out */
 int32_t cpm_last_kernel_ms(cpm_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
-/* algorithmic HBM bytes of one hourly sampler launch */
+/* algorithmic HBM bytes of one hourly sampler launch, with the element
+ * size of the rows the selected kernel really streams (4-byte high words on the default grouped
+ * path, 8-byte f64 otherwise) */
 int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *ctx, int64_t *bytes_out);
+/* diagnostic: the categorical draw (src/resampling.jl:38-45) of the grouped zone sampler for the
+ * given 53-bit uniforms (u = k * 2^-53) against the installed row p_dest[origin,:,hour], through
+ * the sampler's own staging, high-word tree walk and exact-row fallback.  dest_out[i] = 1-based
+ * destination, or 0 for an all-zero row (the sampler then keeps the origin, :35-36);
+ * *n_exact_out = how many draws took the exact (f64 row) fallback. */
+int32_t cpm_debug_categorical(cpm_ctx *ctx, int64_t origin1, int64_t hour1, int64_t n, const uint64_t *k53,
+                              int64_t *dest_out, int32_t *n_exact_out_or_null);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,20 @@ from conftest import SIM_SEED, TABLE_SEED
 pytestmark = pytest.mark.gpu
 
 KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
-           pytest.param(4, id="zone_strided"), pytest.param(5, id="zone_grouped")]
+           pytest.param(4, id="zone_strided"), pytest.param(5, id="zone_grouped"),
+           pytest.param(55, id="zone_grouped_gen5"), pytest.param(56, id="zone_grouped_256x4")]
+
+
+def _set_kernel(s, kernel):
+    """55 / 56: the grouped path's first generation (f64 rows) / its 256-thread x 4-car sampler shape."""
+    if kernel == 55:
+        s.set_kernel(5)
+        s.set_option(5, 5)
+    elif kernel == 56:
+        s.set_kernel(5)
+        s.set_option(6, 1)
+    else:
+        s.set_kernel(kernel)
 
 
 def _tables(O, Z, T=24, seed=TABLE_SEED):
@@ -52,7 +65,7 @@ def test_ivp_and_counts_bit_exact(cpm, O, kernel, Z, cpz):
     p_drive, p_dest = _tables(O, Z, T)
     ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), want_state=True)
     with cpm.Sampler(Z, T) as s:
-        s.set_kernel(kernel)
+        _set_kernel(s, kernel)
         s.set_p_drive(p_drive)
         s.set_p_dest(p_dest)
         s.init_states(C, cpz)
@@ -114,7 +127,7 @@ def test_travel_time_sum_bit_exact(cpm, O, kernel):
     p_dest = O.createpdestin(dm, Z, T, 2)
     ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
     with cpm.Sampler(Z, T) as s:
-        s.set_kernel(kernel)
+        _set_kernel(s, kernel)
         s.set_p_drive(p_drive)
         s.set_p_dest(p_dest)
         s.set_datamatrix(dm, dist)
@@ -151,7 +164,7 @@ def test_edge_rows(cpm, O, kernel):
     init = O.solveinitialvalueproblem(st, tr, p_drive, p_dest, C, Z, SIM_SEED)
     assert np.array_equal(init, ref["zone0"])
     with cpm.Sampler(Z, T) as s:
-        s.set_kernel(kernel)
+        _set_kernel(s, kernel)
         s.set_p_drive(p_drive)
         s.set_p_dest(p_dest)
         s.init_states(C, cpz)
@@ -204,7 +217,7 @@ def test_shards_sum_to_the_single_run(cpm, O, kernel):
         pk = np.zeros((Z, T), dtype=np.int64)
         dr = np.zeros((Z, T), dtype=np.int64)
         with cpm.Sampler(Z, T) as s:
-            s.set_kernel(kernel)
+            _set_kernel(s, kernel)
             s.set_p_drive(p_drive)
             s.set_p_dest(p_dest)
             for rank in range(world):
@@ -312,7 +325,7 @@ def test_headline_config_full_size(cpm, O):
         assert (r["parking"].sum(axis=0) == C).all()
         np.testing.assert_allclose(r["parking"] / C, ref["parking"] / C, rtol=1e-6, atol=0)
         for kernel in (1, 2, 4):  # the other kernels agree at full size too
-            s.set_kernel(kernel)
+            _set_kernel(s, kernel)
             r2 = s.resample(SIM_SEED)
             assert np.array_equal(r2["parking"], ref["parking"]) and np.array_equal(r2["driving"], ref["driving"])
         s.set_kernel(0)
@@ -388,7 +401,7 @@ def test_extreme_skew_everyone_to_one_zone(cpm, O, kernel):
     p_dest[:, 2, :] = 1.0
     ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
     with cpm.Sampler(Z, T) as s:
-        s.set_kernel(kernel)
+        _set_kernel(s, kernel)
         s.set_p_drive(p_drive)
         s.set_p_dest(p_dest)
         s.init_states(C, cpz)
@@ -415,7 +428,7 @@ def test_fixed_stride_overflow_is_reported_and_auto_demotes_itself(cpm, O):
         s.init_states(C, cpz)
         counts = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
         for kernel in (5, 4):
-            s.set_kernel(kernel)
+            _set_kernel(s, kernel)
             s.resample_dev(SIM_SEED, counts.data_ptr())
             s.sync()
             assert int(counts[-1].item()) != 0
@@ -437,6 +450,35 @@ def test_fixed_stride_overflow_is_reported_and_auto_demotes_itself(cpm, O):
         assert np.array_equal(pk2, r["parking"])
 
 
+def test_run_overflow_of_the_grouped_layout_falls_back(cpm, O):
+    """Every car of a zone drives into ONE destination group (a permutation of the groups, so no bucket outgrows its
+    region): the zone's fixed-size run of that group (scap = a quarter of the bucket region) overflows as soon as the
+    zone holds more than scap cars.  Async form: status word; blocking form: exact layout, bit-exact counts."""
+    import torch
+    Z, T, cpz = 64, 24, 3200
+    C = Z * cpz
+    p_drive = np.ones((Z, T), order="F")
+    p_dest = np.zeros((Z, Z, T), order="F")
+    for o in range(Z):
+        g = (o // 2 + 1) % 32
+        p_dest[o, 2 * g, :] = 0.5
+        p_dest[o, 2 * g + 1, :] = 0.5
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    assert ref["parking"].max() < 4 * cpz  # no bucket overflow: it is the run that overflows
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(5)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        counts = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
+        s.resample_dev(SIM_SEED, counts.data_ptr())
+        s.sync()
+        assert int(counts[-1].item()) != 0
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+    assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
+
+
 def test_few_cars_per_zone_uses_the_car_kernel_and_matches(cpm, O):
     """AUTO below 32 cars/zone (streaming every row would not pay): still bit-exact."""
     Z, T, cpz = 300, 24, 5
@@ -450,3 +492,74 @@ def test_few_cars_per_zone_uses_the_car_kernel_and_matches(cpm, O):
         assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
         r = s.resample(SIM_SEED)
     assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
+
+
+def _ref_categorical(cdf_row, k53):
+    """first j with u <= cdf[j] after the D1 clamp (oracle semantics), 1-based; 0 for an all-zero row"""
+    last = cdf_row[-1]
+    if last == 0.0:
+        return np.zeros(len(k53), dtype=np.int64)
+    u = k53.astype(np.float64) * 2.0 ** -53  # exact: k < 2^53
+    ue = np.where(u == 0.0, np.float64(5e-324), u)
+    ue = np.minimum(ue, last)
+    return np.searchsorted(cdf_row, ue, side="left").astype(np.int64) + 1
+
+
+def test_high_word_search_equals_the_f64_search_on_ties_and_edges(cpm, O):
+    """The grouped sampler searches the 4-byte high words of the CDF and falls back to the f64 row on a tie
+    or above the row total (cpm_zone6_kernels.h).  Draws are placed exactly on, just below and just above
+    every breakpoint, in rows built to hold many equal high words, zero-probability zones, a row total
+    below 1, a row total above 1 and an all-zero row."""
+    Z, T = 300, 2
+    rng = np.random.default_rng(7)
+    p = np.zeros((Z, Z, T), order="F")
+    w = rng.random(Z) ** 2
+    w[rng.random(Z) < 0.3] = 0.0              # zero-probability zones (leading / trailing ones included)
+    w[:3] = 0.0
+    w[-2:] = 0.0
+    p[0, :, 0] = w / w.sum()
+    tiny = np.full(Z, 2.0 ** -40)             # 300 breakpoints sharing few high words (steps of 2^-40)
+    tiny[0] = 0.25
+    p[1, :, 0] = tiny
+    p[2, :, 0] = (w / w.sum()) * 0.5          # row total 0.5: half of the draws lie above it (D1: last zone with p > 0)
+    p[3, :, 0] = (w / w.sum()) * 1.5          # row total above 1: saturated high words
+    # row 4 stays all zero; row 5: everything in the last zone; row 6: everything in the first zone
+    p[5, Z - 1, 0] = 1.0
+    p[6, 0, 0] = 1.0
+    p[7, :, 0] = 2.0 ** -60                   # every high word 0 except through accumulation: all ties
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(np.full((Z, T), 0.5, order="F"))
+        s.set_p_dest(p)
+        total_exact = 0
+        for o in range(1, 9):
+            cdf = s.get_cdf_row(o, 1)
+            assert np.array_equal(cdf, np.cumsum(p[o - 1, :, 0]))  # sequential f64 sum (numpy cumsum is sequential)
+            t53 = np.floor(np.minimum(cdf, 1.0 - 2.0 ** -53) * 2.0 ** 53).astype(np.uint64)
+            ks = [np.array([0, 1, 2, 2 ** 53 - 1, 2 ** 53 - 2, 2 ** 52, 2 ** 21, 2 ** 21 - 1, 2 ** 21 + 1], dtype=np.uint64)]
+            for d in (-2 ** 21, -1, 0, 1, 2 ** 21 - 1, 2 ** 21):
+                ks.append(np.clip(t53.astype(np.int64) + d, 0, 2 ** 53 - 1).astype(np.uint64))
+            ks.append(rng.integers(0, 2 ** 53, size=5000, dtype=np.uint64))
+            k53 = np.concatenate(ks)
+            got, n_exact = s.debug_categorical(o, 1, k53)
+            want = _ref_categorical(cdf, k53)
+            assert np.array_equal(got, want), (o, np.flatnonzero(got != want)[:5])
+            total_exact += n_exact
+        assert total_exact > 1000  # the fallback really ran
+
+
+def test_high_word_table_rows_longer_than_a_power_of_two(cpm, O):
+    """Z = 2^H and Z = 2^H + 1: the tree's special slots (element Z-1 in tree[0], pads)."""
+    rng = np.random.default_rng(11)
+    for Z in (64, 65, 127, 128, 129):
+        p = np.zeros((Z, Z, 1), order="F")
+        w = rng.random(Z)
+        p[0, :, 0] = w / w.sum()
+        with cpm.Sampler(Z, 1) as s:
+            s.set_p_drive(np.full((Z, 1), 0.5, order="F"))
+            s.set_p_dest(p)
+            cdf = s.get_cdf_row(1, 1)
+            t53 = np.floor(np.minimum(cdf, 1.0 - 2.0 ** -53) * 2.0 ** 53).astype(np.int64)
+            k53 = np.concatenate([np.clip(t53 + d, 0, 2 ** 53 - 1) for d in (-1, 0, 1)] +
+                                 [rng.integers(0, 2 ** 53, size=2000)]).astype(np.uint64)
+            got, _ = s.debug_categorical(1, 1, k53)
+            assert np.array_equal(got, _ref_categorical(cdf, k53)), Z

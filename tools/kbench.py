@@ -34,6 +34,12 @@ for cfg in args.configs.split(","):
     s.set_kernel({"car": 1, "zone": 2, "strided": 4, "grouped": 5}[kern])
     _lib.check(L.cpm_set_option(s._h, 3, int(block)))
     _lib.check(L.cpm_set_option(s._h, 100, int(abl)))
+    if len(parts) > 3 and parts[3]:
+        _lib.check(L.cpm_set_option(s._h, 4, int(parts[3])))  # grouped path: place-kernel shape (82, 162, ...)
+    if len(parts) > 4 and parts[4]:
+        _lib.check(L.cpm_set_option(s._h, 5, int(parts[4])))  # grouped path: generation (5 | 6)
+    if len(parts) > 5 and parts[5]:
+        _lib.check(L.cpm_set_option(s._h, 6, int(parts[5])))  # generation 6: sampler shape (0 | 1)
     r = s.resample(0x5EEDCA125)
     s.set_profile(True)
     s.sync()
