@@ -25,7 +25,7 @@ CPM_FLAG_TRAVEL = 1
 CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
 CPM_KERNEL_ZONE_STRIDED, CPM_KERNEL_ZONE_GROUPED = 4, 5
 CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
-CPM_OPT_PLACE_SHAPE, CPM_OPT_GROUPED_GEN, CPM_OPT_SAMPLER_SHAPE = 4, 5, 6
+CPM_OPT_PLACE_SHAPE, CPM_OPT_GROUPED_GEN = 4, 5
 
 _lib = None
 

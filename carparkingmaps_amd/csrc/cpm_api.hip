@@ -65,7 +65,7 @@ struct cpm_ctx {
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
     double *d_cdf = nullptr;     // [T][Z][Zp]
-    uint32_t *d_hi = nullptr;    // [T][Z][Zq] high words of the CDF (cpm_zone6_kernels.h)
+    uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_zone6_kernels.h)
     double *d_last = nullptr;    // [T][Z] row totals
     int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
@@ -159,13 +159,17 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
     int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)",
                                 CPM_ERR_TABLE);
     if (rc != CPM_OK) return rc;
-    if (cpm::zone6_row_fits(static_cast<int>(c->Z))) {  // the high-word table of the grouped zone path
+    if (cpm::zone6_row_fits(static_cast<int>(c->Z))) {  // the row packs (guide + high words) of the grouped zone path
         const int64_t rows = c->T * c->Z;
-        if (!c->d_hi) HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * static_cast<size_t>(rows) * c->Zq));
+        const int G = cpm::pack_guide_bits(static_cast<int>(c->Z));
+        const size_t words = static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, G);
+        if (!c->d_hi) HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * words));
         if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
         const unsigned gy = static_cast<unsigned>(std::min<int64_t>(rows, 32768)), gz = static_cast<unsigned>((rows + gy - 1) / gy);
         hipLaunchKernelGGL(cpm::k_build_hi32, dim3(nblk(c->Zq, 256), gy, gz), dim3(256), 0, c->stream, c->d_cdf, c->d_hi, c->d_last,
-                           static_cast<int>(c->Z), c->Zp, c->Zq, rows);
+                           static_cast<int>(c->Z), c->Zp, c->Zq, G, rows);
+        hipLaunchKernelGGL(cpm::k_build_guide, dim3(nblk((int64_t(1) << G) + 8, 256), gy, gz), dim3(256), 0, c->stream, c->d_hi,
+                           static_cast<int>(c->Z), c->Zq, G, rows);
         HIP_TRY(hipGetLastError());
     }
     c->have_cdf = true;
@@ -498,10 +502,6 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     case CPM_OPT_GROUPED_GEN:
         if (value != 5 && value != 6) return fail(CPM_ERR_ARG, "grouped generation %lld", (long long)value);
         c->zw5.v6 = (value == 6);
-        return CPM_OK;
-    case CPM_OPT_SAMPLER_SHAPE:
-        if (value < 0 || value > 2) return fail(CPM_ERR_ARG, "sampler shape %lld", (long long)value);
-        c->zw5.shape6 = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_ABLATE:
         c->zw.ablate = static_cast<int>(value);
@@ -847,7 +847,8 @@ int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
     // its true element size is substituted, as 8(d) prescribes for a variant with a different element size.
     const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zw5.v6 && c->d_hi &&
                          cpm::zone6_path_fits(c->Zp, c->n, static_cast<int>(c->Z));
-    const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(c->Zq) * 4 + c->Z * 8 : c->Z * c->Z * 8;
+    const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))) * 4 + c->Z * 8
+                                 : c->Z * c->Z * 8;
     *bytes_out = rows + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
     return CPM_OK;
 }
@@ -871,12 +872,13 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
     if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(int), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, k53, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        const int H = cpm::tree_height(static_cast<int>(c->Z));
-        const size_t lds = sizeof(uint32_t) * (size_t(1) << H);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_zone6_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(cpm::k_zone6_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * c->Zq, c->d_last + row,
-                           c->d_cdf + row * c->Zp, static_cast<int>(c->Z), c->Zq, H, n, d_k, d_o, d_n);
+        const int G = cpm::pack_guide_bits(static_cast<int>(c->Z));
+        const size_t words = static_cast<size_t>(cpm::pack_row_words(c->Zq, G));
+        const size_t lds = sizeof(uint32_t) * words;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_zone6_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(cpm::k_zone6_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
+                           c->d_cdf + row * c->Zp, static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
         e = hipGetLastError();
     }
     int h_n = 0;

@@ -35,8 +35,9 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
         uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
         uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
         uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
-        uint32_t n0 = hi1 ^ c1 ^ k0;
-        uint32_t n2 = hi0 ^ c3 ^ k1;
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96 = a ^ b ^ c; hipcc emits two v_xor otherwise)
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, k0, c1, 0x96);
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, k1, c3, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += kPhiloxW0; k1 += kPhiloxW1;
     }

@@ -347,13 +347,15 @@ inline void zone5_launch_place(hipStream_t stream, int bpg, int deep, const uint
 
 // run capacity of the second-generation layout: a quarter of a bucket region (= the mean bucket size), >= 64, whole 128-B lines
 inline uint32_t zone6_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
-// packed driver = id | (dest - group start) << idbits
-inline uint32_t zone6_idbits(int zpg)
+// second generation: groups of 2^gshift consecutive zones, at most kGroups of them
+inline uint32_t zone6_gshift(int Z)
 {
-    int gbits = 1;
-    while ((1 << gbits) < zpg) ++gbits;
-    return static_cast<uint32_t>(32 - gbits);
+    uint32_t s = 0;
+    while ((static_cast<int64_t>(kGroups) << s) < Z) ++s;
+    return s;
 }
+// packed driver = id | (dest mod 2^gshift) << idbits
+inline uint32_t zone6_idbits(int Z) { return 32u - std::max(1u, zone6_gshift(Z)); }
 
 struct Zone5Work {
     Zone3Work base;  // bucket arrays, cached initial bucketing, sampler launcher state
@@ -365,10 +367,9 @@ struct Zone5Work {
     int bpg = kBlocksPerGroup, deep = 2;  // k_zone5_place shape (CPM_OPT_PLACE_SHAPE, A/B runs)
     // second generation (cpm_zone6_kernels.h): high-word rows, fixed-size runs
     bool v6 = true;              // CPM_OPT_GROUPED_GEN: 6 (default) or 5
-    int shape6 = 0;              // sampler shape, see zone6_launch
     uint32_t *Dq = nullptr;      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;    // [Z][kGroups] run lengths
-    uint32_t scap = 0, idbits = 0;
+    uint32_t scap = 0, idbits = 0, gshift6 = 0;
     int64_t n = 0;
     int Z = 0, T = 0;
 
@@ -407,7 +408,8 @@ struct Zone5Work {
         e = hipMalloc(&D, sizeof(uint2) * static_cast<size_t>(Z) * base.cap);
         if (e == hipSuccess) e = hipMalloc(&offz, sizeof(uint32_t) * static_cast<size_t>(Z) * (kGroups + 1));
         scap = zone6_scap(base.cap);
-        idbits = zone6_idbits(zpg);
+        idbits = zone6_idbits(Z);
+        gshift6 = zone6_gshift(Z);
         if (e == hipSuccess) e = hipMalloc(&Dq, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups * scap);
         if (e == hipSuccess) e = hipMalloc(&cntg, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups);
         if (e != hipSuccess) release();
@@ -429,8 +431,7 @@ inline bool zone6_path_fits(int Zp, int64_t n, int Z)
     if (!zone5_path_fits(Zp, n, Z) || !zone6_row_fits(Z)) return false;
     const int64_t mean = (n + Z - 1) / Z;
     const uint32_t cap = static_cast<uint32_t>((std::max<int64_t>(4 * mean, 1024) + 63) / 64 * 64);
-    const int zpg = (Z + kGroups - 1) / kGroups;
-    return n <= (int64_t(1) << zone6_idbits(zpg)) && static_cast<int64_t>(Z) * kGroups * zone6_scap(cap) * 4 <= (int64_t(16) << 30);
+    return n <= (int64_t(1) << zone6_idbits(Z)) && (1 << zone6_gshift(Z)) <= kMaxZonesPerGroup6 && static_cast<int64_t>(Z) * kGroups * zone6_scap(cap) * 4 <= (int64_t(16) << 30);
 }
 
 template <bool TRAVEL, int NP>
@@ -539,7 +540,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             Zone6Args b;
             b.ids = ids;
             b.cnt = cnt;
-            b.hi_t = d_hi + static_cast<size_t>(t) * Z * Zq;
+            b.rp_t = d_hi + static_cast<size_t>(t) * Z * pack_row_words(Zq, pack_guide_bits(Z));
             b.last_t = d_last + static_cast<size_t>(t) * Z;
             b.pdrive_t = pd;
             b.cdf_t = cdf;
@@ -556,24 +557,23 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             b.Z = Z;
             b.Zp = Zp;
             b.Zq = Zq;
-            b.H = H;
+            b.G = pack_guide_bits(Z);
             b.T = T;
             b.t = t;
-            b.zpg = w5.zpg;
             b.cap = w.cap;
             b.scap = w5.scap;
             b.idbits = w5.idbits;
             b.step = step;
-            b.gmagic = w5.gmagic;
+            b.gshift = w5.gshift6;
             b.car_begin = car_begin;
             b.seed = seed;
             b.abl = w.sampler.ablate;
             prof_begin(t);
-            if (last_hour) zone6_launch<false>(b, travel, w5.shape6, cu_count, stream);
-            else zone6_launch<true>(b, travel, w5.shape6, cu_count, stream);
+            if (last_hour) zone6_launch<false>(b, travel, stream);
+            else zone6_launch<true>(b, travel, stream);
             prof_end(t);
             if (!last_hour) {
-                zone6_launch_place(stream, w5.bpg, w5.Dq, w5.cntg, w5.zpg, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
+                zone6_launch_place(stream, w5.bpg, w5.Dq, w5.cntg, 1 << w5.gshift6, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
                 ids = ids_next;
                 cnt = cnt_next;
             }

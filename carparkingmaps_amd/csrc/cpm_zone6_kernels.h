@@ -1,8 +1,14 @@
 // cpm_zone6_kernels.h -- second generation of the grouped zone path (CPM_KERNEL_ZONE_GROUPED):
-//   * the row a workgroup stages is the HIGH WORD of the CDF row, 4 B per destination instead of 8;
-//   * the drivers of an origin zone go into FIXED-SIZE runs, one per destination group, so their
-//     position is known the moment their rank is (no scan, no second pass over the cars, no
-//     offsets for the placing kernel to fetch before it can fetch the runs).
+//   * the row a workgroup stages is the HIGH WORD of the CDF row, 4 B per destination instead of 8, preceded by a
+//     GUIDE table (cut-point method) so that a draw costs ~2 LDS probes instead of a 12-level tree walk;
+//   * the drivers of an origin zone go into FIXED-SIZE runs, one per destination group, so their position is
+//     known the moment their rank is (no scan, no second pass over the cars, no offsets for the placing
+//     kernel to fetch before it can fetch the runs).
+// Why: measured with ablations (tools/micro/sampler_bench.hip, profiles/round1_notes.md) the sampler is bound by
+// VALU issue (~650 vector instructions per thread and zone, ~4 cycles each), not by HBM (a kernel that only streams
+// the same bytes takes 14.6 us against 40) and not by latency (prefetching the next zone's registers in resident
+// workgroups changed nothing).  So the layout in HBM is chosen to make the instructions few: the row arrives in the
+// order it is used in (a straight 16-B copy into LDS, no per-element index arithmetic) and the search is short.
 //
 // High-word rows.  The categorical draw of src/resampling.jl:38-45 is "first j with u <= cdf[j]"
 // with u = k * 2^-53, k the 53 high bits of two Philox words.  Let hi[j] = floor(cdf[j] * 2^32)
@@ -12,15 +18,18 @@
 // so the first j with hi[j] >= khi IS the reference's answer whenever hi[j] > khi strictly.  When
 // hi[j] == khi (probability ~ Z * 2^-32 per draw), or no hi[j] >= khi exists (u above the row total),
 // the car repeats the search on the f64 row in HBM with exactly the code of the other kernels
-// (clamp_u + lower_bound_row).  u == 0 needs no special case: khi = 0, the walk stops at the first j,
+// (clamp_u + lower_bound_row).  u == 0 needs no special case: khi = 0, the scan stops at the first j,
 // hi[0] > 0 is accepted (cdf[0] > 0: the clamped answer), hi[0] == 0 is a tie.  Results are bit-identical
 // to the f64 search by construction; tests/test_gpu_parity.py drives the tie and out-of-range branches
-// through cpm_debug_categorical.  The table hi[T][Z][Zq] (Zq = Z rounded up to 32, padded with
-// 0xFFFFFFFF) and the row totals last[T][Z] are built next to the CDF.  HBM traffic of an hourly
-// launch: Z*Zq*4 B of rows instead of Z*Zp*8.
+// through cpm_debug_categorical.
+// Guide.  guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G - 1 (u16; G = guide bits, 2^G >= Z by
+// default).  The answer of a draw lies in [guide[m], guide[m+1]], m = khi >> (32 - G): every j' < guide[m] has
+// hi[j'] < m << (32-G) <= khi, and hi[guide[m+1]] >= (m+1) << (32-G) > khi; a lower bound inside that bracket finds it.
+// A row pack = [2^G + 8 u16 guide][Zq u32 hi] (Zq = Z rounded up to 32, padded with 0xFFFFFFFF), built next
+// to the CDF; HBM traffic of an hourly launch: Z * (2^G * 2 + Zq * 4) B of rows instead of Z * Zp * 8.
 //
 // Fixed-size runs.  Zone z's drivers of destination group g are written at D[(z*kGroups + g)*scap + rank],
-// rank from an LDS atomic, as id | (dest - g*zpg) << idbits (4 B; needs n <= 2^idbits).  The 32 run
+// (groups of 2^gshift consecutive zones), rank from an LDS atomic, as id | (dest mod 2^gshift) << idbits (4 B; n <= 2^idbits).  The 32 run
 // lengths go to cntg[z][32].  A run that would outgrow scap raises bit 1 of the status word, as a bucket
 // outgrowing cap does; the caller repeats the step on the exact layout.
 #pragma once
@@ -37,12 +46,32 @@
 namespace cpm {
 
 constexpr int kGroups6 = 32;            // destination groups (== kGroups of cpm_zone5_kernels.h)
-constexpr int kMaxZonesPerGroup6 = 512;
+constexpr int kMaxZonesPerGroup6 = 1024;
 constexpr uint32_t kHiMax = 0xFFFFFFFFu;
 
-// hi[t][o][:] and last[t][o] from the canonical CDF (one thread per element, coalesced both ways)
-__global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ cdf, uint32_t *__restrict__ hi,
-                                                    double *__restrict__ last, int Z, int Zp, int Zq, int64_t rows)
+// row pack geometry: guide words (two u16 entries per word), then Zq high words
+__host__ __device__ inline int pack_guide_bits(int Z)
+{
+    int g = 3;  // >= 8 entries: the guide is a whole number of 16-B pieces
+    while ((1 << g) < Z) ++g;
+    // a quarter of an entry per destination: measured best at S4k (entries per destination 1: 32.0 us, 1/2: 29.9, 1/4: 29.1 --
+    // the shorter pack (18 instead of 24 KiB of HBM and LDS per zone) outweighs the ~2 extra probes of a draw)
+#ifndef CPM_GUIDE_SHIFT
+#define CPM_GUIDE_SHIFT 2
+#endif
+    g = g - CPM_GUIDE_SHIFT < 3 ? 3 : g - CPM_GUIDE_SHIFT;
+    return g;
+}
+__host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4; }  // 2^G + 1 entries used (+7 pad: whole 16-B pieces)
+__host__ __device__ inline int pack_row_words(int Zq, int G)  // at least 1 KiB: one whole LDS-DMA wave-instruction
+{
+    const int w = pack_guide_words(G) + Zq;
+    return w < 256 ? 256 : w;
+}
+
+// hi part of every row pack and last[t][o], from the canonical CDF (one thread per element, coalesced both ways)
+__global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ cdf, uint32_t *__restrict__ rp,
+                                                    double *__restrict__ last, int Z, int Zp, int Zq, int G, int64_t rows)
 {
     const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
     if (row >= rows) return;
@@ -54,13 +83,41 @@ __global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ c
         if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated by k_build_cdf)
         if (j == Z - 1) last[row] = c;
     }
-    hi[row * Zq + j] = h;
+    rp[row * pack_row_words(Zq, G) + pack_guide_words(G) + j] = h;
+}
+
+// guide part: guide[m] = min(first j in [0, Z) with hi[j] >= m << (32 - G), Z - 1), m = 0 .. 2^G (entry 2^G and the pad: Z - 1)
+__global__ __launch_bounds__(256) void k_build_guide(uint32_t *__restrict__ rp, int Z, int Zq, int G, int64_t rows)
+{
+    const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
+    if (row >= rows) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= (1 << G) + 8) return;
+    uint32_t *pack = rp + row * pack_row_words(Zq, G);
+    const uint32_t *hi = pack + pack_guide_words(G);
+    int lo = Z - 1;
+    if (m < (1 << G)) {
+        const uint32_t edge = static_cast<uint32_t>(m) << (32 - G);
+        int n = Z;
+        lo = 0;
+        while (n > 0) {
+            const int half = n >> 1;
+            if (hi[lo + half] < edge) {
+                lo += half + 1;
+                n -= half + 1;
+            } else {
+                n = half;
+            }
+        }
+        lo = min(lo, Z - 1);
+    }
+    reinterpret_cast<uint16_t *>(pack)[m] = static_cast<uint16_t>(lo);
 }
 
 struct Zone6Args {
     const uint32_t *ids;      // [Z*cap] this hour's buckets
     const uint32_t *cnt;      // [Z] their sizes
-    const uint32_t *hi_t;     // [Z][Zq] high words of this hour's CDF rows
+    const uint32_t *rp_t;     // [Z][RW] row packs of this hour: guide, then the high words of the CDF row
     const double *last_t;     // [Z] row totals (f64)
     const double *pdrive_t, *cdf_t, *dm;
     uint32_t *ids_next;       // [Z*cap]       (grouped)
@@ -69,49 +126,53 @@ struct Zone6Args {
     uint32_t *cntg;           // [Z][kGroups6] run lengths (grouped)
     uint32_t *rec_out;        // [Z*cap] dest | drive << 31 per slot (plain form)
     unsigned long long *parking_t, *driving_t, *tt_sum, *status;
-    int Z, Zp, Zq, H, T, t, zpg;
-    uint32_t cap, scap, idbits, step, gmagic;
+    int Z, Zp, Zq, G, T, t;  // G: guide bits; RW = 2^G / 2 + Zq words per row pack
+    uint32_t cap, scap, idbits, step, gshift;  // destination group = dest >> gshift (2^gshift zones per group, at most 32 groups)
     int64_t car_begin;
     uint64_t seed;
+    unsigned long long *stamps;  // CPM_DIAGNOSTIC builds only: [Z][8] s_memtime stamps of wave 0 (tools/micro/sampler_bench.hip)
     int abl;  // CPM_DIAGNOSTIC builds only (results WRONG): 1 no Philox, 2 no walk, 4 no emit stores, 8 no row load, 16 no ids load,
               // 32 no per-car work at all (everybody stays), 64 no tree build, 128 no rank atomics
 };
 
 #ifdef CPM_DIAGNOSTIC
 #define CPM_ABL(a, bit) ((a).abl & (bit))
+#define CPM_STAMP(a, z, k)                                                                    \
+    do {                                                                                       \
+        if ((a).stamps && threadIdx.x == 0) (a).stamps[static_cast<size_t>(z) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define CPM_ABL(a, bit) 0
+#define CPM_STAMP(a, z, k) \
+    do {                   \
+    } while (0)
 #endif
 
-// request the row: NQ 16-B pieces per thread (clamped: every lane issues every load)
+// Row pack -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR destination, no ds_write; one wave-instruction moves
+// 64 x 16 B to 1 KiB of consecutive LDS.  The destination is wave-uniform base + lane x 16, the source is per lane.
+// Counts in vmcnt like any load.  NQ (compile time) >= pieces / BLOCK wave-instructions per wave: with a static count
+// the compiler can wait for the OLDER id loads alone (s_waitcnt vmcnt(NQ)) and run Philox while the pack is landing.
 template <int BLOCK, int NQ>
-__device__ __forceinline__ void hi_row_load(uint4 (&pc)[NQ], const uint32_t *hi_row, int Zq, int tid)
+__device__ __forceinline__ void pack_dma(uint32_t *lds, const uint32_t *pack, int pieces, int tid)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(hi_row);
-#pragma unroll
-    for (int m = 0; m < NQ; ++m) pc[m] = src[min(tid + m * BLOCK, Zq / 4 - 1)];
-}
-
-// pieces -> breadth-first tree over elements 0..Z-2; tree[0] = element Z-1; ranks >= Z-1 of the tree = 0xFFFFFFFF
-template <int BLOCK, int NQ>
-__device__ __forceinline__ void hi_tree_store(uint32_t *tree, const uint4 (&pc)[NQ], int Z, int Zq, int H, int tid)
-{
-    const int P = 1 << H;
-    for (int r = Z + tid; r < P; r += BLOCK) {
-        int tz = __builtin_ctz(static_cast<unsigned>(r));
-        tree[(1u << (H - 1 - tz)) + (static_cast<unsigned>(r) >> (tz + 1))] = kHiMax;
-    }
+    // Every wave issues exactly NQ instructions, unpredicated (so that the count is known at compile time): chunk k
+    // = 64 pieces from min(64 k, pieces - 64); chunks past the end repeat the last one (same bytes to the same LDS words).
+    // pieces >= 64: a pack is at least 1 KiB (pack_row_words).
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int m = 0; m < NQ; ++m) {
-        const int j = tid + m * BLOCK;
-        if (4 * j < Zq) {
-            const uint32_t el = 4 * j;
-            const uint32_t q[4] = {pc[m].x, pc[m].y, pc[m].z, pc[m].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (el + k < static_cast<uint32_t>(Z)) tree[eytz_pos(el + k, Z, H)] = q[k];
-        }
+        const int p0 = min((m * (BLOCK / 64) + wave) * 64, pieces - 64);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(pack) + p0 + lane,
+                                         (__attribute__((address_space(3))) void *)(lds + 4 * p0), 16, 0, 0);
     }
+}
+
+// s_waitcnt vmcnt(NQ) carrying the id registers as in/out operands (see k_zone6_sample)
+template <int N, int NQ>
+__device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
+{
+    static_assert(N == 5 && NQ <= 63, "written for CPT = 4");
+    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]) : "n"(NQ) : "memory");
 }
 
 // The f64 search of the other kernels, on the row where it lies in HBM (rare: ties and u above the row total).
@@ -120,33 +181,50 @@ __device__ __noinline__ uint32_t search_exact_row(const double *__restrict__ cdf
     return static_cast<uint32_t>(lower_bound_row(cdf_row, Z, clamp_u(uc, last)));
 }
 
-// CPT simultaneous tree walks; ok[c] = the answer is certain (strictly greater high word)
+// CPT draws against the staged pack, in lockstep (CPT independent LDS reads in flight per step):
+// dest[c] = first j with hi[j] >= khi[c], ok[c] = the answer is certain (hi[dest] > khi).  want[c] == false: no search.
+// The guide brackets the answer: j in [guide[m], guide[m+1]], m = khi >> sh (entries are clamped to Z-1 and a draw above
+// the row's last high word never searches, so the bracket is in range); then a branch-free lower bound inside the bracket,
+// O(log bracket) whatever the row looks like (long runs of equal values -- zero-probability zones -- included).
 template <int CPT>
-__device__ __forceinline__ void hi_walk(const uint32_t *tree, const uint32_t (&khi)[CPT], int Z, int H, uint32_t hi_last,
-                                        uint32_t (&dest)[CPT], bool (&ok)[CPT])
+__device__ __forceinline__ void pack_search(const uint16_t *guide, const uint32_t *hi, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
+                                            int sh, uint32_t hi_last, uint32_t (&dest)[CPT], bool (&ok)[CPT])
 {
-    uint32_t i[CPT], cand[CPT];
+    uint32_t lo[CPT], n[CPT], any = 0;
+    bool in[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        i[c] = 1;
-        cand[c] = kHiMax;
+        in[c] = want[c] && khi[c] <= hi_last;
+        const uint32_t m = in[c] ? khi[c] >> sh : 0u;
+        lo[c] = guide[m];
+        n[c] = guide[m + 1];
     }
-    for (int l = 0; l < H; ++l) {
-        uint32_t k[CPT];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) k[c] = tree[i[c]];
+    for (int c = 0; c < CPT; ++c) {
+        n[c] = in[c] ? n[c] - lo[c] : 0u;
+        any |= n[c];
+    }
+    while (__any(any != 0)) {  // wave-uniform trips: the longest bracket of the wave
+        uint32_t v[CPT], idx[CPT], half[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const bool right = k[c] < khi[c];
-            cand[c] = right ? cand[c] : k[c];  // value of the last node where the walk went left = value at the answer
-            i[c] = 2 * i[c] + (right ? 1u : 0u);
+            half[c] = n[c] >> 1;
+            idx[c] = lo[c] + half[c];
+            v[c] = hi[idx[c]];
+        }
+        any = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const bool lt = n[c] != 0 && v[c] < khi[c];
+            lo[c] = lt ? idx[c] + 1 : lo[c];
+            n[c] = lt ? n[c] - half[c] - 1 : half[c];
+            any |= n[c];
         }
     }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        dest[c] = eytz_decode(i[c], Z, H);
-        if (dest[c] == static_cast<uint32_t>(Z - 1)) cand[c] = hi_last;  // element Z-1 lives in tree[0], its tree slot holds the pad
-        ok[c] = cand[c] > khi[c];
+        dest[c] = lo[c];
+        ok[c] = in[c] && hi[lo[c]] > khi[c];
     }
 }
 
@@ -160,40 +238,54 @@ __device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint
     chi = r.w;
 }
 
-// One workgroup per origin zone.  (Resident workgroups each walking several zones were measured no faster -- a zone's
-// time is its chain of memory round trips, not the dispatch of its waves -- and cost registers.)
+// One workgroup per origin zone.  (Resident workgroups each walking several zones, with or without the next zone's
+// registers prefetched, were measured no faster; profiles/round1_notes.md.)
 // GROUPED: stayers compacted into next hour's bucket of the zone, drivers into the zone's fixed-size runs.  The drivers
 // of a zone are first ranked and staged in LDS (kStage6 entries per group) and written out by 16 lanes per run,
 // 64 B at a time; ranks beyond kStage6 go to HBM directly.
 // !GROUPED: dest | drive << 31 per slot (the last hour of a resample: counts only).
-// The bucket size, the ids and the row are requested together: the id loads are clamped to the zone's REGION (cap), not
-// to its size, so they do not wait for the size (one HBM round trip less in every workgroup's chain).
+// Order of a workgroup's life (in-kernel stamps, S4k: loads 3.5 us, Philox 1.0, search 2.3, emit 1.2, rest 1.1 before
+// this ordering): the bucket size, the ids and the row pack are requested together (the id loads are clamped to the
+// zone's REGION, not to its size, so they do not wait for the size); Philox runs while the pack is landing; after the
+// barrier the CPT cars of a thread search in lockstep and take their slots with one stayer ticket per wave and CPT
+// rank atomics in flight together.
 constexpr int kStage6 = 32;
 
-template <bool TRAVEL, int BLOCK, int NQ, int CPT, bool GROUPED>
-__global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : 8) void k_zone6_sample(Zone6Args a)
+#ifndef CPM_WPS
+#define CPM_WPS 8
+#endif
+template <bool TRAVEL, int BLOCK, int CPT, int NQ, bool GROUPED>
+__global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zone6Args a)
 {
-    extern __shared__ uint32_t tree[];  // 2^H high words
+    extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
     __shared__ uint32_t s_ndrive, s_nstay;
     __shared__ unsigned long long s_tt;
     __shared__ uint32_t gb[kGroups6];
     __shared__ uint32_t stage[GROUPED ? kGroups6 * kStage6 : 1];
-    const int Z = a.Z, H = a.H;
+    const int Z = a.Z;
     const int z = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    // ids first, then the row: vmcnt retires in order, so the ids have landed when the row has
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    CPM_STAMP(a, z, 0);
+    // The id loads are written in assembly and waited for by hand: with LDS-DMA in flight hipcc (ROCm 7.2) drains
+    // vmcnt to 0 at the first use of any ordinary load result, which would put Philox behind the whole pack.  Here the
+    // wave issues CPT + 1 id loads, then exactly NQ LDS-DMA instructions; vmcnt retires in order, so vmcnt <= NQ means the
+    // ids are in their registers.  (The waitcnt statement names the ids as in/out operands: no use can move above it.)
+    const uint32_t n_raw = a.cnt[z];  // (scalar loads: requested before the statements below fence memory operations)
+    const double last = a.last_t[z];
+    const double pd = a.pdrive_t[z];
     uint32_t id[CPT + 1];
 #pragma unroll
-    for (int c = 0; c <= CPT; ++c) id[c] = CPM_ABL(a, 16) ? b + tid + c * BLOCK : a.ids[b + min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1)];
-    uint4 pc[NQ];
-    if (!CPM_ABL(a, 8)) hi_row_load<BLOCK, NQ>(pc, a.hi_t + static_cast<size_t>(z) * a.Zq, a.Zq, tid);
-    else
-        for (int m = 0; m < NQ; ++m) pc[m] = make_uint4(tid * 4u << 18, (tid * 4u + 1) << 18, (tid * 4u + 2) << 18, (tid * 4u + 3) << 18);
-    const uint32_t n = min(a.cnt[z], cap);
-    const double last = a.last_t[z];
-    const long long thr = bernoulli_threshold(a.pdrive_t[z]);
+    for (int c = 0; c <= CPT; ++c) {
+        const uint32_t *src = a.ids + b + min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(id[c]) : "v"(src) : "memory");
+    }
+    pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
+    wait_ids<CPT + 1, NQ>(id);
+    const uint32_t n = min(n_raw, cap);
+    const long long thr = bernoulli_threshold(pd);
     if (tid == 0) {
         a.parking_t[z] = n;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         s_ndrive = 0;
@@ -208,97 +300,130 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : 8) void k_zone6_sample(Zone6Arg
         }
         return;
     }
-    if (!CPM_ABL(a, 64)) hi_tree_store<BLOCK, NQ>(tree, pc, Z, a.Zq, H, tid);
+    // Philox of the register-resident cars: needs the ids only
+    bool valid[CPT], drive[CPT], want[CPT], ok[CPT];
+    uint32_t dest[CPT], clo[CPT], khi[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
+        long long kb;
+        if (CPM_ABL(a, 1)) {
+            clo[c] = id[c] * 2654435761u;
+            khi[c] = (id[c] ^ a.step) * 2246822519u;
+            kb = static_cast<long long>(clo[c]) << 21;
+        } else {
+            car_draw_words(a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step, kb, clo[c], khi[c]);
+        }
+        drive[c] = valid[c] && (kb <= thr);
+        want[c] = drive[c] && last != 0.0;  // stays, or zero row: destination = origin (:35-36)
+    }
+    CPM_STAMP(a, z, 1);
     __syncthreads();
-    const uint32_t hi_last = tree[0];
+    CPM_STAMP(a, z, 2);
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
+    const uint32_t hi_last = hi[Z - 1];
     const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t nd = 0;
     long long tt = 0;
     uint32_t *stay_out = GROUPED ? a.ids_next + static_cast<size_t>(z) * cap : nullptr;
     uint32_t *runs = GROUPED ? a.D + static_cast<size_t>(z) * kGroups6 * a.scap : nullptr;
-
-    auto emit = [&](uint32_t q, uint32_t idc, bool valid, bool drive, uint32_t dest) {
-        if (GROUPED) {
-            const unsigned long long mS = __ballot(valid && !drive);
-            uint32_t bS = 0;
-            if (lane == 0 && mS) bS = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(mS)));
-            bS = __shfl(bS, 0, 64);
-            if (valid && !drive && !CPM_ABL(a, 4)) stay_out[bS + static_cast<uint32_t>(__popcll(mS & below))] = idc;
-            if (drive) {
-                const uint32_t g = (dest * a.gmagic) >> 24;
-                const uint32_t rank = atomicAdd(&gb[g], 1u);
-                const uint32_t packed = idc | ((dest - g * static_cast<uint32_t>(a.zpg)) << a.idbits);
-                if (rank < static_cast<uint32_t>(kStage6) && !CPM_ABL(a, 128)) stage[g * kStage6 + rank] = packed;
-                else if (rank < a.scap) runs[g * a.scap + rank] = packed;
-            }
-        } else {
-            if (valid) a.rec_out[b + q] = dest | (drive ? kDriveBit : 0u);
-        }
-    };
-
-    if (CPM_ABL(a, 32)) {
-        if (tid == 0) s_nstay = n;
-    } else {  // CPT cars per thread, straight line
-        bool valid[CPT], drive[CPT], ok[CPT], any_search = false;
-        uint32_t dest[CPT], clo[CPT], khi[CPT];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
-            long long kb;
-            if (CPM_ABL(a, 1)) {
-                clo[c] = id[c] * 2654435761u;
-                khi[c] = (id[c] ^ a.step) * 2246822519u;
-                kb = static_cast<long long>(clo[c]) << 21;
-            } else {
-                car_draw_words(a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step, kb, clo[c], khi[c]);
-            }
-            drive[c] = valid[c] && (kb <= thr);
-            any_search |= drive[c] && last != 0.0;
-        }
+    CPM_STAMP(a, z, 3);
+    if (!CPM_ABL(a, 32)) {
         if (CPM_ABL(a, 2)) {
 #pragma unroll
-            for (int c = 0; c < CPT; ++c) dest[c] = drive[c] ? (khi[c] >> 8) % static_cast<uint32_t>(Z) : z;
-        } else if (__any(any_search)) {
-            hi_walk<CPT>(tree, khi, Z, H, hi_last, dest, ok);
-#pragma unroll
             for (int c = 0; c < CPT; ++c) {
-                if (!(drive[c] && last != 0.0)) dest[c] = z;  // stays, or zero row: destination = origin (:35-36)
-                else if (!ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
+                dest[c] = (khi[c] >> 8) % static_cast<uint32_t>(Z);
+                ok[c] = true;
             }
         } else {
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) dest[c] = z;
+            pack_search<CPT>(guide, hi, khi, want, sh, hi_last, dest, ok);
         }
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            emit(tid + c * BLOCK, id[c], valid[c], drive[c], dest[c]);
+            if (!want[c]) dest[c] = z;
+            else if (!ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
             if (drive[c]) {
                 ++nd;
                 if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step);
             }
         }
+        CPM_STAMP(a, z, 4);
+        if (GROUPED) {
+            // stayers: one ticket per wave for all its CPT slots
+            unsigned long long mS[CPT];
+            uint32_t total = 0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                mS[c] = __ballot(valid[c] && !drive[c]);
+                total += static_cast<uint32_t>(__popcll(mS[c]));
+            }
+            uint32_t bS = 0;
+            if (lane == 0 && total) bS = atomicAdd(&s_nstay, total);
+            bS = __shfl(bS, 0, 64);
+            // drivers: CPT rank atomics in flight together
+            uint32_t rank[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                if (valid[c] && !drive[c]) stay_out[bS + static_cast<uint32_t>(__popcll(mS[c] & below))] = id[c];
+                bS += static_cast<uint32_t>(__popcll(mS[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                if (drive[c]) {
+                    const uint32_t g = dest[c] >> a.gshift;
+                    const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                    if (rank[c] < static_cast<uint32_t>(kStage6)) stage[g * kStage6 + rank[c]] = packed;
+                    else if (rank[c] < a.scap) runs[g * a.scap + rank[c]] = packed;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (valid[c]) a.rec_out[b + tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
+        }
+    } else if (tid == 0) {
+        s_nstay = n;
     }
     for (uint32_t q0 = CPT * BLOCK; q0 < n && !CPM_ABL(a, 32); q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
         const uint32_t q = q0 + tid;
-        const bool valid = q < n;
-        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid ? a.ids[b + q] : 0u);
+        const bool valid1 = q < n;
+        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q] : 0u);
         const uint64_t car = static_cast<uint64_t>(a.car_begin) + idx;
         long long kb;
-        uint32_t clo1[1], khi1[1], dest1[1] = {static_cast<uint32_t>(z)};
-        bool ok1[1];
+        uint32_t clo1[1], khi1[1], dest1[1];
+        bool ok1[1], want1[1];
         car_draw_words(a.seed, car, a.step, kb, clo1[0], khi1[0]);
-        const bool drive = valid && (kb <= thr);
-        if (drive && last != 0.0) {
-            hi_walk<1>(tree, khi1, Z, H, hi_last, dest1, ok1);
-            if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
-        }
-        if (drive) {
+        const bool drive1 = valid1 && (kb <= thr);
+        want1[0] = drive1 && last != 0.0;
+        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, dest1, ok1);
+        if (!want1[0]) dest1[0] = z;
+        else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
+        if (drive1) {
             if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest1[0], a.seed, car, a.step);
             ++nd;
         }
-        emit(q, idx, valid, drive, dest1[0]);
+        if (GROUPED) {
+            const unsigned long long m1 = __ballot(valid1 && !drive1);
+            uint32_t b1 = 0;
+            if (lane == 0 && m1) b1 = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(m1)));
+            b1 = __shfl(b1, 0, 64);
+            if (valid1 && !drive1) stay_out[b1 + static_cast<uint32_t>(__popcll(m1 & below))] = idx;
+            if (drive1) {
+                const uint32_t g = dest1[0] >> a.gshift;
+                const uint32_t rank = atomicAdd(&gb[g], 1u);
+                const uint32_t packed = idx | ((dest1[0] & ((1u << a.gshift) - 1u)) << a.idbits);
+                if (rank < static_cast<uint32_t>(kStage6)) stage[g * kStage6 + rank] = packed;
+                else if (rank < a.scap) runs[g * a.scap + rank] = packed;
+            }
+        } else {
+            if (valid1) a.rec_out[b + q] = dest1[0] | (drive1 ? kDriveBit : 0u);
+        }
     }
+    CPM_STAMP(a, z, 5);
     for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
     if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
     if (TRAVEL) {
@@ -306,6 +431,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : 8) void k_zone6_sample(Zone6Arg
         if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
     }
     __syncthreads();  // ranks, staged drivers and counters are final
+    CPM_STAMP(a, z, 6);
     if (GROUPED) {
         // staged drivers -> their runs: 16 lanes per group, 64 B per store
         for (int g = tid >> 4; g < kGroups6; g += BLOCK / 16) {
@@ -323,195 +449,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : 8) void k_zone6_sample(Zone6Arg
         if (GROUPED) a.cnt_next[z] = s_nstay;  // k_zone6_place adds the arrivals
         if (TRAVEL && s_tt) atomicAdd(a.tt_sum, s_tt);
     }
-}
-
-// Pipelined form of k_zone6_sample (GROUPED only): as many workgroups as are resident at once, each walking the zones
-// z = blockIdx.x, blockIdx.x + gridDim.x, ...  While a zone is being sampled, the ids, row and scalars of the
-// workgroup's NEXT zone are already on their way into registers, so no HBM round trip sits between two zones
-// (with one workgroup per zone a zone's time was its chain of round trips -- size/ids/row in, stores drained before
-// s_endpgm -- times Z / resident workgroups).  Every global store of a zone is issued in its flush phase, AFTER the
-// next zone's registers have been consumed: the sampling phase keeps stayers and drivers in LDS (kStay7 / kStage6 entries
-// per zone / per group; what does not fit goes to HBM directly), so the wait for the prefetched registers never
-// covers a store that has just been issued (vmcnt retires in order).
-constexpr int kStay7 = 1536;
-
-template <bool TRAVEL, int BLOCK, int NQ, int CPT, int WPS>
-__global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : WPS) void k_zone7_sample(Zone6Args a)
-{
-    extern __shared__ uint32_t tree[];  // 2^H high words
-    __shared__ uint32_t s_ndrive[2], s_nstay[2];
-    __shared__ unsigned long long s_tt[2];
-    __shared__ uint32_t gb[2][kGroups6];
-    __shared__ uint32_t stage[kGroups6 * kStage6];
-    __shared__ uint32_t stay[kStay7];
-    const int Z = a.Z, H = a.H;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t cap = a.cap;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int stride = gridDim.x;
-    int z = blockIdx.x;
-    if (z >= Z) return;
-    // registers of the zone about to be sampled (prefetch target)
-    uint32_t idn[CPT + 1];
-    uint4 pc[NQ];
-    uint32_t n_raw;
-    double last_raw, pd_raw;
-    auto prefetch = [&](int zz) {
-        const uint32_t bb = static_cast<uint32_t>(zz) * cap;
-#pragma unroll
-        for (int c = 0; c <= CPT; ++c) idn[c] = a.ids[bb + min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1)];
-        hi_row_load<BLOCK, NQ>(pc, a.hi_t + static_cast<size_t>(zz) * a.Zq, a.Zq, tid);
-        n_raw = a.cnt[zz];
-        last_raw = a.last_t[zz];
-        pd_raw = a.pdrive_t[zz];
-    };
-    prefetch(z);
-    int par = 0;
-    // consume the prefetched registers of zone z: tree, counters, scalars
-    uint32_t id[CPT + 1], n;
-    double last;
-    long long thr;
-    auto consume = [&]() {
-        n = min(n_raw, cap);
-        last = last_raw;
-        thr = bernoulli_threshold(pd_raw);
-#pragma unroll
-        for (int c = 0; c <= CPT; ++c) id[c] = idn[c];
-        hi_tree_store<BLOCK, NQ>(tree, pc, Z, a.Zq, H, tid);
-        if (tid == 0) {
-            s_ndrive[par] = 0;
-            s_nstay[par] = 0;
-            s_tt[par] = 0;
-        }
-        if (tid < kGroups6) gb[par][tid] = 0;
-    };
-    consume();
-    {
-        const int zn = z + stride;
-        prefetch(zn < Z ? zn : z);  // (a harmless repeat of the same zone at the end keeps the code path uniform)
-    }
-    while (true) {
-        __syncthreads();  // A: tree and counters of zone z are in place
-        const uint32_t b = static_cast<uint32_t>(z) * cap;
-        const uint32_t hi_last = tree[0];
-        const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
-        uint32_t nd = 0;
-        long long tt = 0;
-        uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
-        uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups6 * a.scap;
-
-        auto emit = [&](uint32_t idc, bool valid, bool drive, uint32_t dest) {
-            const unsigned long long mS = __ballot(valid && !drive);
-            uint32_t bS = 0;
-            if (lane == 0 && mS) bS = atomicAdd(&s_nstay[par], static_cast<uint32_t>(__popcll(mS)));
-            bS = __shfl(bS, 0, 64);
-            if (valid && !drive) {
-                const uint32_t pos = bS + static_cast<uint32_t>(__popcll(mS & below));
-                if (pos < static_cast<uint32_t>(kStay7)) stay[pos] = idc;
-                else stay_out[pos] = idc;
-            }
-            if (drive) {
-                const uint32_t g = (dest * a.gmagic) >> 24;
-                const uint32_t rank = atomicAdd(&gb[par][g], 1u);
-                const uint32_t packed = idc | ((dest - g * static_cast<uint32_t>(a.zpg)) << a.idbits);
-                if (rank < static_cast<uint32_t>(kStage6)) stage[g * kStage6 + rank] = packed;
-                else if (rank < a.scap) runs[g * a.scap + rank] = packed;
-            }
-        };
-
-        if (n > 0) {
-            bool valid[CPT], drive[CPT], ok[CPT], any_search = false;
-            uint32_t dest[CPT], clo[CPT], khi[CPT];
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
-                long long kb;
-                car_draw_words(a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step, kb, clo[c], khi[c]);
-                drive[c] = valid[c] && (kb <= thr);
-                any_search |= drive[c] && last != 0.0;
-            }
-            if (__any(any_search)) {
-                hi_walk<CPT>(tree, khi, Z, H, hi_last, dest, ok);
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) {
-                    if (!(drive[c] && last != 0.0)) dest[c] = z;  // stays, or zero row: destination = origin (:35-36)
-                    else if (!ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) dest[c] = z;
-            }
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) {
-                emit(id[c], valid[c], drive[c], dest[c]);
-                if (drive[c]) {
-                    ++nd;
-                    if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step);
-                }
-            }
-            for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
-                const uint32_t q = q0 + tid;
-                const bool valid1 = q < n;
-                const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q] : 0u);
-                const uint64_t car = static_cast<uint64_t>(a.car_begin) + idx;
-                long long kb;
-                uint32_t clo1[1], khi1[1], dest1[1] = {static_cast<uint32_t>(z)};
-                bool ok1[1];
-                car_draw_words(a.seed, car, a.step, kb, clo1[0], khi1[0]);
-                const bool drive1 = valid1 && (kb <= thr);
-                if (drive1 && last != 0.0) {
-                    hi_walk<1>(tree, khi1, Z, H, hi_last, dest1, ok1);
-                    if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
-                }
-                if (drive1) {
-                    if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest1[0], a.seed, car, a.step);
-                    ++nd;
-                }
-                emit(idx, valid1, drive1, dest1[0]);
-            }
-            for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
-            if (lane == 0 && nd) atomicAdd(&s_ndrive[par], nd);
-            if (TRAVEL) {
-                for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
-                if (lane == 0 && tt) atomicAdd(&s_tt[par], static_cast<unsigned long long>(tt));
-            }
-        }
-        __syncthreads();  // B: ranks, staged cars and counters of zone z are final; nobody reads the tree any more
-        const int zdone = z, pdone = par;
-        const uint32_t ndone = n;
-        const int znext = z + stride;
-        const bool more = znext < Z;
-        if (more) {  // the next zone's registers -> tree / counters (other set), then ITS next zone's loads
-            par ^= 1;
-            z = znext;
-            consume();
-            const int zn2 = z + stride;
-            prefetch(zn2 < Z ? zn2 : z);
-        }
-        // flush zone zdone: every global store of the zone happens here
-        {
-            uint32_t *so = a.ids_next + static_cast<size_t>(zdone) * cap;
-            uint32_t *ru = a.D + static_cast<size_t>(zdone) * kGroups6 * a.scap;
-            const uint32_t ns = min(s_nstay[pdone], static_cast<uint32_t>(kStay7));
-            for (uint32_t i = tid; i < ns; i += BLOCK) so[i] = stay[i];
-            for (int g = tid >> 4; g < kGroups6; g += BLOCK / 16) {
-                const uint32_t lim = min(gb[pdone][g], static_cast<uint32_t>(kStage6));
-                for (uint32_t i = tid & 15; i < lim; i += 16) ru[g * a.scap + i] = stage[g * kStage6 + i];
-            }
-            if (tid < kGroups6) {
-                const uint32_t c = gb[pdone][tid];
-                a.cntg[static_cast<size_t>(zdone) * kGroups6 + tid] = min(c, a.scap);
-                if (c > a.scap) atomicOr(a.status, 2ull);
-            }
-            if (tid == 0) {
-                a.parking_t[zdone] = ndone;
-                a.driving_t[zdone] = s_ndrive[pdone];
-                a.cnt_next[zdone] = s_nstay[pdone];  // k_zone6_place adds the arrivals
-                if (TRAVEL && s_tt[pdone]) atomicAdd(a.tt_sum, s_tt[pdone]);
-            }
-        }
-        if (!more) break;
-    }
+    CPM_STAMP(a, z, 7);
 }
 
 // Drivers of destination group g -> their buckets.  blockIdx = j * kGroups6 + g: the blocks of a group share
@@ -608,112 +546,88 @@ inline void zone6_launch_place(hipStream_t stream, int bpg, const uint32_t *D, c
         hipLaunchKernelGGL((k_zone6_place<8, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
 }
 
-template <bool TRAVEL, int BLOCK, int CPT, bool GROUPED, int NQ>
+constexpr int kBlock6 = 256, kCpt6 = 4;  // measured at S4k: 512 x 2: 31 us, 256 x 4: 28, 128 x 8: 44
+
+template <bool TRAVEL, bool GROUPED, int NQ>
 inline void zone6_launch_nq(const Zone6Args &a, size_t lds, hipStream_t stream)
 {
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, BLOCK, NQ, CPT, GROUPED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_zone6_sample<TRAVEL, BLOCK, NQ, CPT, GROUPED>), dim3(a.Z), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>), dim3(a.Z), dim3(kBlock6), lds, stream, a);
 }
 
-template <bool TRAVEL, int BLOCK, int CPT, bool GROUPED>
-inline void zone6_launch_b(const Zone6Args &a, hipStream_t stream)
+template <bool TRAVEL, bool GROUPED>
+inline void zone6_launch_t(const Zone6Args &a, hipStream_t stream)
 {
-    const size_t lds = sizeof(uint32_t) * (size_t(1) << a.H);
-    const int need = (a.Zq / 4 + BLOCK - 1) / BLOCK;
-    if (need <= 1) zone6_launch_nq<TRAVEL, BLOCK, CPT, GROUPED, 1>(a, lds, stream);
-    else if (need <= 2) zone6_launch_nq<TRAVEL, BLOCK, CPT, GROUPED, 2>(a, lds, stream);
-    else if (need <= 4) zone6_launch_nq<TRAVEL, BLOCK, CPT, GROUPED, 4>(a, lds, stream);
-    else if (need <= 8) zone6_launch_nq<TRAVEL, BLOCK, CPT, GROUPED, 8>(a, lds, stream);
-    else zone6_launch_nq<TRAVEL, BLOCK, CPT, GROUPED, 16>(a, lds, stream);
+    const int words = pack_row_words(a.Zq, a.G);
+    const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
+    const int need = (words / 4 + kBlock6 - 1) / kBlock6;
+    if (need <= 1) zone6_launch_nq<TRAVEL, GROUPED, 1>(a, lds, stream);
+    else if (need <= 2) zone6_launch_nq<TRAVEL, GROUPED, 2>(a, lds, stream);
+    else if (need <= 3) zone6_launch_nq<TRAVEL, GROUPED, 3>(a, lds, stream);
+    else if (need <= 4) zone6_launch_nq<TRAVEL, GROUPED, 4>(a, lds, stream);
+    else if (need <= 5) zone6_launch_nq<TRAVEL, GROUPED, 5>(a, lds, stream);
+    else if (need <= 6) zone6_launch_nq<TRAVEL, GROUPED, 6>(a, lds, stream);
+    else if (need <= 8) zone6_launch_nq<TRAVEL, GROUPED, 8>(a, lds, stream);
+    else if (need <= 12) zone6_launch_nq<TRAVEL, GROUPED, 12>(a, lds, stream);
+    else if (need <= 20) zone6_launch_nq<TRAVEL, GROUPED, 20>(a, lds, stream);
+    else zone6_launch_nq<TRAVEL, GROUPED, 40>(a, lds, stream);
 }
 
-template <bool TRAVEL, int NQ, int WPS>
-inline void zone7_launch_nq(const Zone6Args &a, size_t lds, int cu_count, hipStream_t stream)
-{
-    static bool attr_done = false;
-    static int resident = 0;
-    const void *fn = reinterpret_cast<const void *>(k_zone7_sample<TRAVEL, 512, NQ, 2, WPS>);
-    if (!attr_done && lds > 32 * 1024) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        attr_done = true;
-    }
-    if (resident == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, lds) != hipSuccess || nb < 1) nb = 1;
-        resident = nb;
-    }
-    const int grid = static_cast<int>(std::min<int64_t>(a.Z, static_cast<int64_t>(resident) * cu_count));
-    hipLaunchKernelGGL((k_zone7_sample<TRAVEL, 512, NQ, 2, WPS>), dim3(grid), dim3(512), lds, stream, a);
-}
-
-template <bool TRAVEL, int WPS>
-inline void zone7_launch(const Zone6Args &a, int cu_count, hipStream_t stream)
-{
-    const size_t lds = sizeof(uint32_t) * (size_t(1) << a.H);
-    const int need = (a.Zq / 4 + 511) / 512;
-    if (need <= 1) zone7_launch_nq<TRAVEL, 1, WPS>(a, lds, cu_count, stream);
-    else if (need <= 2) zone7_launch_nq<TRAVEL, 2, WPS>(a, lds, cu_count, stream);
-    else if (need <= 4) zone7_launch_nq<TRAVEL, 4, WPS>(a, lds, cu_count, stream);
-    else if (need <= 8) zone7_launch_nq<TRAVEL, 8, WPS>(a, lds, cu_count, stream);
-    else zone7_launch_nq<TRAVEL, 16, WPS>(a, lds, cu_count, stream);
-}
-
-// shape: 0 = 512 threads x 2 cars, 1 = 256 threads x 4 cars (travel-time form: 512 x 2 only), 2 = pipelined resident
-// workgroups (k_zone7_sample; GROUPED only)
 template <bool GROUPED>
-inline void zone6_launch(const Zone6Args &a, bool travel, int shape, int cu_count, hipStream_t stream)
+inline void zone6_launch(const Zone6Args &a, bool travel, hipStream_t stream)
 {
-    if (GROUPED && shape >= 2) {
-        if (travel) zone7_launch<true, 2>(a, cu_count, stream);
-        else if (shape == 2) zone7_launch<false, 8>(a, cu_count, stream);
-        else if (shape == 3) zone7_launch<false, 6>(a, cu_count, stream);
-        else zone7_launch<false, 4>(a, cu_count, stream);
-    } else if (travel) zone6_launch_b<true, 512, 2, GROUPED>(a, stream);
-    else if (shape == 1 && a.Zq / 4 <= 16 * 256) zone6_launch_b<false, 256, 4, GROUPED>(a, stream);
-    else zone6_launch_b<false, 512, 2, GROUPED>(a, stream);
+    if (travel) zone6_launch_t<true, GROUPED>(a, stream);
+    else zone6_launch_t<false, GROUPED>(a, stream);
 }
 
-// rows of at most 16 pieces x 512 threads x 4 words, trees of at most 128 KiB
-inline bool zone6_row_fits(int Z) { return Z >= 2 && Z <= 32768; }
+// a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
+inline bool zone6_row_fits(int Z)
+{
+    if (Z < 2 || Z > 32768) return false;
+    const int Zq = (Z + 31) / 32 * 32;
+    return sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, pack_guide_bits(Z))) <= 150 * 1024;
+}
 
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
-// installed row, through the same staging, walk and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
-__global__ __launch_bounds__(512) void k_zone6_search_debug(const uint32_t *__restrict__ hi_row, const double *__restrict__ last_p,
-                                                            const double *__restrict__ cdf_row, int Z, int Zq, int H, int64_t n,
+// installed row, through the same staging, search and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
+__global__ __launch_bounds__(512) void k_zone6_search_debug(const uint32_t *__restrict__ pack_g, const double *__restrict__ last_p,
+                                                            const double *__restrict__ cdf_row, int Z, int Zq, int G, int64_t n,
                                                             const uint64_t *__restrict__ k53, int64_t *__restrict__ out,
                                                             int *__restrict__ n_exact)
 {
-    extern __shared__ uint32_t tree[];
+    extern __shared__ uint32_t pack[];
     const int tid = threadIdx.x;
-    const uint4 *src = reinterpret_cast<const uint4 *>(hi_row);
-    for (int j = tid; j < Zq / 4; j += 512) {
-        uint4 pc[1] = {src[j]};
-        const uint32_t q[4] = {pc[0].x, pc[0].y, pc[0].z, pc[0].w};
-        for (int k = 0; k < 4; ++k)
-            if (4 * j + k < Z) tree[eytz_pos(4 * j + k, Z, H)] = q[k];
-    }
-    for (int r = Z + tid; r < (1 << H); r += 512) {
-        int tz = __builtin_ctz(static_cast<unsigned>(r));
-        tree[(1u << (H - 1 - tz)) + (static_cast<unsigned>(r) >> (tz + 1))] = kHiMax;
+    const int gw = pack_guide_words(G), pieces = pack_row_words(Zq, G) / 4, sh = 32 - G;
+    {
+        const int lane = tid & 63;
+        for (int p0 = tid - lane; p0 < pieces; p0 += 512) {  // wave-uniform trips
+            const int p = p0 + lane;
+            if (p < pieces)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(pack_g) + p,
+                                                 (__attribute__((address_space(3))) void *)(pack + 4 * p0), 16, 0, 0);
+        }
     }
     __syncthreads();
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
     const double last = *last_p;
-    const uint32_t hi_last = tree[0];
+    const uint32_t hi_last = hi[Z - 1];
     for (int64_t i = tid; i < n; i += 512) {
         const uint64_t k = k53[i] & ((1ull << 53) - 1ull);
-        const uint32_t khi[1] = {static_cast<uint32_t>(k >> 21)};
-        uint32_t dest[1];
-        bool ok[1];
         if (last == 0.0) {
             out[i] = 0;
             continue;
         }
-        hi_walk<1>(tree, khi, Z, H, hi_last, dest, ok);
+        uint32_t dest[1];
+        bool ok[1];
+        const uint32_t khi[1] = {static_cast<uint32_t>(k >> 21)};
+        const bool want[1] = {true};
+        pack_search<1>(guide, hi, khi, want, sh, hi_last, dest, ok);
         if (!ok[0]) {
             dest[0] = search_exact_row(cdf_row, Z, static_cast<double>(k) * 0x1.0p-53, last);
             atomicAdd(n_exact, 1);

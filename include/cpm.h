@@ -70,7 +70,6 @@ extern "C" {
 #define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
 #define CPM_OPT_PLACE_SHAPE 4   /* tuning: grouped path, blocks per destination group * 10 + pairs per lane (82, 81, 162, 161) */
 #define CPM_OPT_GROUPED_GEN 5   /* A/B: 6 (default) = high-word rows + fixed-size runs, 5 = first generation (f64 rows) */
-#define CPM_OPT_SAMPLER_SHAPE 6 /* tuning: generation-6 sampler, 0 = 512 threads x 2 cars, 1 = 256 threads x 4 cars */
 #define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;

@@ -9,17 +9,14 @@ pytestmark = pytest.mark.gpu
 
 KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
            pytest.param(4, id="zone_strided"), pytest.param(5, id="zone_grouped"),
-           pytest.param(55, id="zone_grouped_gen5"), pytest.param(56, id="zone_grouped_256x4")]
+           pytest.param(55, id="zone_grouped_gen5")]
 
 
 def _set_kernel(s, kernel):
-    """55 / 56: the grouped path's first generation (f64 rows) / its 256-thread x 4-car sampler shape."""
+    """55: the grouped path's first generation (f64 rows, per-zone offsets)."""
     if kernel == 55:
         s.set_kernel(5)
         s.set_option(5, 5)
-    elif kernel == 56:
-        s.set_kernel(5)
-        s.set_option(6, 1)
     else:
         s.set_kernel(kernel)
 

@@ -38,8 +38,7 @@ for cfg in args.configs.split(","):
         _lib.check(L.cpm_set_option(s._h, 4, int(parts[3])))  # grouped path: place-kernel shape (82, 162, ...)
     if len(parts) > 4 and parts[4]:
         _lib.check(L.cpm_set_option(s._h, 5, int(parts[4])))  # grouped path: generation (5 | 6)
-    if len(parts) > 5 and parts[5]:
-        _lib.check(L.cpm_set_option(s._h, 6, int(parts[5])))  # generation 6: sampler shape (0 | 1)
+
     r = s.resample(0x5EEDCA125)
     s.set_profile(True)
     s.sync()
