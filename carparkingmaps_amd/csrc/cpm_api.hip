@@ -495,7 +495,8 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         if (value) c->zw.block = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PLACE_SHAPE:
-        if (value != 81 && value != 82 && value != 161 && value != 162) return fail(CPM_ERR_ARG, "place shape %lld", (long long)value);
+        if (value != 0 && value != 81 && value != 82 && value != 161 && value != 162) return fail(CPM_ERR_ARG, "place shape %lld", (long long)value);
+        if (value && (c->Z + value / 10 - 1) / (value / 10) > 512) return fail(CPM_ERR_ARG, "place shape %lld: too few blocks for %lld zones", (long long)value, (long long)c->Z);
         c->zw5.bpg = static_cast<int>(value / 10);
         c->zw5.deep = static_cast<int>(value % 10);
         return CPM_OK;

@@ -241,6 +241,16 @@ __global__ __launch_bounds__(BLOCK, (!TRAVEL && NP <= 8) ? 8 : 2) void k_zone5_s
     }
 }
 
+// Blocks of the place kernels per destination group: at most 256 origin zones per block (one run per 16 lanes,
+// four runs per thread) from 1024 zones on -- measured at S4k: 8 blocks 16.9 us, 16 blocks 15.3 us.
+inline int place_bpg(int Z)
+{
+    if (Z < 1024) return 8;
+    int b = 16;
+    while (b < 64 && (Z + b - 1) / b > 256) b *= 2;
+    return b;
+}
+
 // Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share
 // blockIdx % 8 (one XCD, one L2; speed only, never correctness).  Block (g, j) gathers the group-g runs of
 // the origin zones [j*zps, (j+1)*zps); 16 lanes per run, KDEEP pairs per lane held in registers.
@@ -364,7 +374,7 @@ struct Zone5Work {
     uint32_t gmagic = 0;
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;  // final buckets of the last IVP (see zone5_resample)
     int zpg = 0;
-    int bpg = kBlocksPerGroup, deep = 2;  // k_zone5_place shape (CPM_OPT_PLACE_SHAPE, A/B runs)
+    int bpg = 0, deep = 2;  // place kernels' shape: blocks per group (0 = place_bpg(Z)) and pairs per lane; CPM_OPT_PLACE_SHAPE
     // second generation (cpm_zone6_kernels.h): high-word rows, fixed-size runs
     bool v6 = true;              // CPM_OPT_GROUPED_GEN: 6 (default) or 5
     uint32_t *Dq = nullptr;      // [Z][kGroups][scap] packed drivers
@@ -421,7 +431,7 @@ inline bool zone5_path_fits(int Zp, int64_t n, int Z)
 {
     const int64_t mean = (n + Z - 1) / Z;
     return zone3_path_fits(Zp, n, Z) && Z <= (1 << kRankShift) && (Z + kGroups - 1) / kGroups <= kMaxZonesPerGroup &&
-           (Z + kBlocksPerGroup - 1) / kBlocksPerGroup <= 8 * kPlaceSeg &&
+           (Z + place_bpg(Z) - 1) / place_bpg(Z) <= 8 * kPlaceSeg &&
            n < (int64_t(1) << 30) && std::max<int64_t>(4 * mean, 1024) + 64 <= (int64_t(1) << (31 - kRankShift));  // rank field
 }
 
@@ -573,7 +583,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             else zone6_launch<true>(b, travel, stream);
             prof_end(t);
             if (!last_hour) {
-                zone6_launch_place(stream, w5.bpg, w5.Dq, w5.cntg, 1 << w5.gshift6, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
+                zone6_launch_place(stream, w5.bpg ? w5.bpg : place_bpg(Z), w5.Dq, w5.cntg, 1 << w5.gshift6, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
                 ids = ids_next;
                 cnt = cnt_next;
             }
@@ -600,7 +610,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             if (travel) zone5_launch<true>(a, lds_tree, stream);
             else zone5_launch<false>(a, lds_tree, stream);
             prof_end(t);
-            zone5_launch_place(stream, w5.bpg, w5.deep, w5.D, w5.offz, w5.zpg, Z, w.cap, cnt_next, ids_next, status);
+            zone5_launch_place(stream, w5.bpg ? w5.bpg : place_bpg(Z), w5.deep, w5.D, w5.offz, w5.zpg, Z, w.cap, cnt_next, ids_next, status);
             ids = ids_next;
             cnt = cnt_next;
         }
