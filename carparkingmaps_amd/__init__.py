@@ -9,13 +9,15 @@ from . import _lib
 from ._lib import (CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_GROUPED, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_STRIDED,
                    CpmError)
 from .sampler import Sampler, device_count, device_info
-from .reference_api import (Params, averagedrivingtime, correctparameters, createpdestin, createpdrive,
-                            initializestates, params, release, resampling, run_dataset, saveresults,
-                            solveinitialvalueproblem, zone_hour_counts)
+from .reference_api import (DeviceArray, Params, averagedrivingtime, correctparameters, createdatamatrix, createpdestin,
+                            createpdrive, createresultsdirectory, initializestates, params, processgeodata, release,
+                            resampling, run_dataset, saveparameters, saveresults, solveinitialvalueproblem,
+                            zone_hour_counts)
 
 __all__ = [
     "Sampler", "device_count", "device_info", "CpmError", "CPM_KERNEL_AUTO", "CPM_KERNEL_CAR",
     "CPM_KERNEL_ZONE_LDS", "CPM_KERNEL_ZONE_STRIDED", "CPM_KERNEL_ZONE_GROUPED", "Params", "params", "createpdrive", "createpdestin", "initializestates",
     "solveinitialvalueproblem", "resampling", "averagedrivingtime", "correctparameters", "saveresults",
-    "zone_hour_counts", "run_dataset", "release",
+    "zone_hour_counts", "run_dataset", "release", "createdatamatrix", "processgeodata", "createresultsdirectory",
+    "saveparameters", "DeviceArray",
 ]

@@ -18,7 +18,8 @@ SYMBOLS = [
     "cpm_build_p_drive", "cpm_build_p_dest", "cpm_get_p_drive", "cpm_get_cdf_row", "cpm_init_states",
     "cpm_set_state", "cpm_get_state", "cpm_solve_ivp", "cpm_resample", "cpm_resample_dev",
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
-    "cpm_debug_categorical",
+    "cpm_debug_categorical", "cpm_createdatamatrix_rows", "cpm_createdatamatrix_csv", "cpm_get_datamatrix",
+    "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv",
 ]
 
 CPM_FLAG_TRAVEL = 1
@@ -94,6 +95,12 @@ def load():
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
     L.cpm_debug_categorical.argtypes = [vp, i64, i64, i64, vp, vp, C.POINTER(i32)]
+    L.cpm_createdatamatrix_rows.argtypes = [vp, i64, vp]
+    L.cpm_createdatamatrix_csv.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    L.cpm_get_datamatrix.argtypes = [vp, vp]
+    L.cpm_parse_uber_csv.argtypes = [C.c_char_p, C.POINTER(i64), vp, i64]
+    L.cpm_set_distance_from_centroids.argtypes = [vp, vp, vp]
+    L.cpm_get_distance.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("cpm_last_error",):

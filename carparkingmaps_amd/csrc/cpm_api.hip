@@ -16,6 +16,7 @@
 #include "cpm_zone_kernels.h"
 #include "cpm_zone3_kernels.h"
 #include "cpm_zone5_kernels.h"
+#include "cpm_ingest.h"
 
 namespace {
 
@@ -70,7 +71,8 @@ struct cpm_ctx {
     int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
     double *d_dist = nullptr;    // [Z][Z]
-    bool have_pdrive = false, have_cdf = false, have_dm = false;
+    bool have_pdrive = false, have_cdf = false, have_dmat = false, have_dist = false;
+    bool have_dm() const { return have_dmat && have_dist; }
     // cars
     int64_t C_total = 0, cpz = 0, car_begin = 0, n = 0;
     uint32_t *d_zone0 = nullptr;  // [n] current zones
@@ -269,7 +271,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         if (rc_ivp != CPM_OK) return rc_ivp;
     }
     bool travel = (flags & CPM_FLAG_TRAVEL) != 0;
-    if (travel && !c->have_dm) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
+    if (travel && !c->have_dm()) return fail(CPM_ERR_STATE, "CPM_FLAG_TRAVEL needs cpm_set_datamatrix");
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
     if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
         c->status_pending = false;
@@ -575,14 +577,161 @@ int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *d
     HIP_TRY(hipMemcpyAsync(c->d_dm, datamatrix, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->have_dm = true;
+    c->have_dmat = true;
+    c->have_dist = true;
+    return CPM_OK;
+}
+
+// createdatamatrix (src/createdatamatrix.jl:3-27) from rows already resident in d_raw (n x 5, column-major)
+static int32_t datamatrix_from_device_rows(cpm_ctx *c, const double *d_raw, int64_t n)
+{
+    const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
+    if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, sizeof(double) * cells * 2));
+    c->have_dmat = false;
+    HIP_TRY(hipMemsetAsync(c->d_dm, 0, sizeof(double) * cells * 2, c->stream));  // zeros(number_zones, number_zones, T, 2) (:7)
+    if (n == 0) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_dmat = true;
+        return CPM_OK;
+    }
+    uint32_t *d_owner = nullptr;
+    HIP_TRY(hipMalloc(&d_owner, sizeof(uint32_t) * cells));
+    hipError_t e = hipMemsetAsync(d_owner, 0, sizeof(uint32_t) * cells, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cpm::k_dm_owner, dim3(nblk(n, 256)), dim3(256), 0, c->stream, d_raw, n, static_cast<int>(c->Z),
+                           static_cast<int>(c->T), d_owner, c->d_err);
+        hipLaunchKernelGGL(cpm::k_dm_write, dim3(nblk(n, 256)), dim3(256), 0, c->stream, d_raw, n, static_cast<int>(c->Z),
+                           static_cast<int>(c->T), d_owner, c->d_dm);
+        e = hipGetLastError();
+    }
+    int32_t rc = (e == hipSuccess) ? check_err_flag(c, "createdatamatrix: a row holds a zone id / hour that is not an integer in range "
+                                                        "(reference: InexactError / BoundsError)", CPM_ERR_ARG)
+                                   : fail(CPM_ERR_HIP, "createdatamatrix: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dfree(d_owner);
+    if (rc == CPM_OK) c->have_dmat = true;
+    return rc;
+}
+
+int32_t cpm_parse_uber_csv(const char *path_to_csv_data, int64_t *n_rows_out, double *rawdata_out, int64_t capacity_rows)
+{
+    if (!path_to_csv_data || !n_rows_out) return fail(CPM_ERR_ARG, "parse_uber_csv: null argument");
+    // the size query and the copy that follows it parse the file once: the rows of the last query are kept per thread
+    thread_local cpm::CsvRows rows;
+    thread_local std::string rows_key;
+    struct stat st;
+    if (stat(path_to_csv_data, &st) != 0) return fail(CPM_ERR_ARG, "parse_uber_csv: %s: %s", path_to_csv_data, strerror(errno));
+    const std::string key = std::string(path_to_csv_data) + "|" + std::to_string(st.st_size) + "|" + std::to_string(st.st_mtim.tv_sec) +
+                            "." + std::to_string(st.st_mtim.tv_nsec);
+    if (key != rows_key) {
+        rows_key.clear();
+        const unsigned hw = std::thread::hardware_concurrency();
+        std::string err = cpm::read_uber_csv(path_to_csv_data, static_cast<int>(std::min(32u, hw ? hw : 4u)), rows, nullptr);
+        if (!err.empty()) return fail(CPM_ERR_ARG, "parse_uber_csv: %s", err.c_str());
+        rows_key = key;
+    }
+    *n_rows_out = rows.n;
+    if (!rawdata_out) return CPM_OK;
+    rows_key.clear();  // handed over below: do not keep a second copy
+    if (capacity_rows < rows.n) return fail(CPM_ERR_ARG, "parse_uber_csv: %lld rows, room for %lld", (long long)rows.n, (long long)capacity_rows);
+    for (int k = 0; k < 5; ++k)
+        std::memcpy(rawdata_out + static_cast<size_t>(k) * capacity_rows, rows.col[k].data(), sizeof(double) * static_cast<size_t>(rows.n));
+    rows = cpm::CsvRows();
+    return CPM_OK;
+}
+
+int32_t cpm_createdatamatrix_rows(cpm_ctx *c, int64_t n_rows, const double *rawdata)
+{
+    CTX_TRY(c);
+    if (n_rows < 0 || n_rows >= (int64_t(1) << 32) - 1 || (n_rows > 0 && !rawdata)) return fail(CPM_ERR_ARG, "createdatamatrix: bad row list");
+    double *d_raw = nullptr;
+    if (n_rows > 0) {
+        HIP_TRY(hipMalloc(&d_raw, sizeof(double) * 5 * n_rows));
+        hipError_t e = hipMemcpyAsync(d_raw, rawdata, sizeof(double) * 5 * n_rows, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            dfree(d_raw);
+            return fail(CPM_ERR_HIP, "createdatamatrix: upload: %s", hipGetErrorString(e));
+        }
+    }
+    int32_t rc = datamatrix_from_device_rows(c, d_raw, n_rows);
+    dfree(d_raw);
+    return rc;
+}
+
+int32_t cpm_createdatamatrix_csv(cpm_ctx *c, const char *path_to_csv_data, int64_t *n_rows_out)
+{
+    CTX_TRY(c);
+    if (!path_to_csv_data) return fail(CPM_ERR_ARG, "createdatamatrix: null path");
+    cpm::CsvRows rows;
+    const unsigned hw = std::thread::hardware_concurrency();
+    std::string err = cpm::read_uber_csv(path_to_csv_data, static_cast<int>(std::min(32u, hw ? hw : 4u)), rows, nullptr);
+    if (!err.empty()) return fail(CPM_ERR_ARG, "createdatamatrix: %s", err.c_str());
+    if (n_rows_out) *n_rows_out = rows.n;
+    if (rows.n >= (int64_t(1) << 32) - 1) return fail(CPM_ERR_ARG, "createdatamatrix: too many rows");
+    double *d_raw = nullptr;
+    if (rows.n > 0) {
+        HIP_TRY(hipMalloc(&d_raw, sizeof(double) * 5 * rows.n));
+        for (int k = 0; k < 5; ++k) {
+            hipError_t e = hipMemcpyAsync(d_raw + static_cast<size_t>(k) * rows.n, rows.col[k].data(), sizeof(double) * rows.n,
+                                          hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(c->stream);
+                dfree(d_raw);
+                return fail(CPM_ERR_HIP, "createdatamatrix: upload: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    int32_t rc = datamatrix_from_device_rows(c, d_raw, rows.n);
+    dfree(d_raw);
+    return rc;
+}
+
+int32_t cpm_get_datamatrix(cpm_ctx *c, double *datamatrix_out)
+{
+    CTX_TRY(c);
+    if (!datamatrix_out) return fail(CPM_ERR_ARG, "null out");
+    if (!c->have_dmat) return fail(CPM_ERR_STATE, "datamatrix not set");
+    HIP_TRY(hipMemcpyAsync(datamatrix_out, c->d_dm, sizeof(double) * c->Z * c->Z * c->T * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CPM_OK;
+}
+
+int32_t cpm_set_distance_from_centroids(cpm_ctx *c, const double *centroid_lat, const double *centroid_long)
+{
+    CTX_TRY(c);
+    if (!centroid_lat || !centroid_long) return fail(CPM_ERR_ARG, "null centroids");
+    const size_t dbytes = sizeof(double) * c->Z * c->Z;
+    if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
+    double *d_ll = nullptr;
+    HIP_TRY(hipMalloc(&d_ll, sizeof(double) * 2 * c->Z));
+    hipError_t e = hipMemcpyAsync(d_ll, centroid_lat, sizeof(double) * c->Z, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ll + c->Z, centroid_long, sizeof(double) * c->Z, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cpm::k_distance, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z)), dim3(256), 0, c->stream, d_ll, d_ll + c->Z,
+                           static_cast<int>(c->Z), c->d_dist);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d_ll);
+    if (e != hipSuccess) return fail(CPM_ERR_HIP, "distance matrix: %s", hipGetErrorString(e));
+    c->have_dist = true;
+    return CPM_OK;
+}
+
+int32_t cpm_get_distance(cpm_ctx *c, double *dist_out)
+{
+    CTX_TRY(c);
+    if (!dist_out) return fail(CPM_ERR_ARG, "null out");
+    if (!c->have_dist) return fail(CPM_ERR_STATE, "distance matrix not set");
+    HIP_TRY(hipMemcpyAsync(dist_out, c->d_dist, sizeof(double) * c->Z * c->Z, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return CPM_OK;
 }
 
 int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive, double *out)
 {
     CTX_TRY(c);
-    if (!c->have_dm) return fail(CPM_ERR_STATE, "build_p_drive: cpm_set_datamatrix first");
+    if (!c->have_dm()) return fail(CPM_ERR_STATE, "build_p_drive: datamatrix and distance matrix first (cpm_set_datamatrix, or cpm_createdatamatrix_* + cpm_set_distance_from_centroids)");
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
     double *d_ms = nullptr;
@@ -603,7 +752,7 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
 int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double *out)
 {
     CTX_TRY(c);
-    if (!c->have_dm) return fail(CPM_ERR_STATE, "build_p_dest: cpm_set_datamatrix first");
+    if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
     double *d_p = nullptr;
     HIP_TRY(hipMalloc(&d_p, bytes));

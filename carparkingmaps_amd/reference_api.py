@@ -11,6 +11,7 @@ Like the reference, the functions read the script-level hyper-parameters implici
 reference does not have: `params.seed` (the reference draws from an unseeded global RNG)
 and `params.device`.
 """
+import json
 import os
 from dataclasses import dataclass
 
@@ -71,11 +72,165 @@ def _ensure(key, s, name, array, setter):
         _loaded[key][name] = fp
 
 
+# ------------------------------------------------------------------------------- data formats
+class DeviceArray:
+    """What createdatamatrix / processgeodata return here instead of a dense host array: the array lives in HBM
+    (6.4 GB + 134 MB at Z = 4096) inside the context of its (number_zones, T, device); `numpy()` downloads it in
+    the reference's layout.  createpdrive / createpdestin / resampling accept it where the reference passes the array."""
+
+    def __init__(self, kind, number_zones):
+        self.kind, self.number_zones = kind, int(number_zones)
+        self.serial = DeviceArray._serial = getattr(DeviceArray, "_serial", 0) + 1
+
+    def numpy(self):
+        s, _ = _sampler(self.number_zones)
+        return s.get_datamatrix() if self.kind == "datamatrix" else s.get_distance()
+
+    @property
+    def shape(self):
+        Z = self.number_zones
+        return (Z, Z, params.T, 2) if self.kind == "datamatrix" else (Z, Z)
+
+
+def createdatamatrix(path_to_csv_data, number_zones):
+    """src/createdatamatrix.jl:3-27: Uber Movement CSV -> datamatrix (Z, Z, T, 2), built in HBM by the native
+    reader (cpm_createdatamatrix_csv).  Returns a DeviceArray."""
+    s, key = _sampler(number_zones)
+    s.createdatamatrix_csv(path_to_csv_data)
+    h = DeviceArray("datamatrix", number_zones)
+    _loaded[key]["dm_device"] = h.serial
+    _loaded[key].pop("dm", None)
+    return h
+
+
+def geojson_vertex_lists(features):
+    """The coordinate walk of src/processgeodata.jl:19-97 -> (number_zones, {zone id: (longitudes, latitudes)}).
+
+    Quirks kept: MOVEMENT_ID is a string of an int; the number of zones comes from the LAST feature's id (+1 when the
+    first id is 0, :12-17); id 0 is stored as number_zones (:22-25); every Float64 LEAF found at depth 1..6 below
+    `coordinates` appends (parent[1], parent[2]) -- so a [long, lat] pair is stored twice, once per leaf, and a leaf that
+    JSON parsed as an integer is skipped (the reference prints a warning from its innermost level); leaves below the
+    fifth list level are never stored (:84: the innermost test looks at `coordinates`, not at the leaf)."""
+    first = int(features[0]["properties"]["MOVEMENT_ID"])
+    last = int(features[-1]["properties"]["MOVEMENT_ID"])
+    number_zones = last + 1 if first == 0 else last
+    zones = {}
+
+    def walk(node, depth):
+        out = []
+        for child in node:
+            if isinstance(child, float):
+                out.append((node[0], node[1]))
+            elif isinstance(child, list) and depth < 5:
+                out.extend(walk(child, depth + 1))
+        return out
+
+    for entry in features:
+        zid = int(entry["properties"]["MOVEMENT_ID"])
+        if zid == 0:
+            zid = number_zones
+        coords = entry["geometry"]["coordinates"]
+        pts = walk(coords, 1) if isinstance(coords, list) else []
+        if len(pts) > 100000:
+            raise IndexError("more than 100000 coordinates in one zone (BoundsError in the reference, :19-20)")
+        zones[zid] = ([p[0] for p in pts], [p[1] for p in pts])  # a later feature with the same id overwrites from column 1
+    return number_zones, zones
+
+
+def polygon_centroids(number_zones, zones, scan=10000):
+    """src/processgeodata.jl:99-146 on the vertex lists: (centroid_lat, centroid_long), zeros for zones without data.
+    The literal loop bound 10000 is kept: vertices beyond it are not seen."""
+    clat = np.zeros(number_zones)
+    clong = np.zeros(number_zones)
+    for zid, (lons, lats) in zones.items():
+        if not (1 <= zid <= number_zones) or not lons or lons[0] == 0:
+            continue
+        lon = list(lons) + [0.0, 0.0, 0.0]
+        lat = list(lats) + [0.0, 0.0, 0.0]
+        if len(lon) < scan + 2:
+            lon += [0.0] * (scan + 2 - len(lon))
+            lat += [0.0] * (scan + 2 - len(lat))
+        summation_term = 0.0
+        for j in range(scan):  # j is 0-based here: element j is the reference's [i, j+1]
+            if lon[j] == 0:
+                summation_term = summation_term - (lat[j - 1] * lon[j] - lat[j] * lon[j - 1])
+                lon[j] = lon[0]
+                lat[j] = lat[0]
+                summation_term = summation_term + (lat[j - 1] * lon[j] - lat[j] * lon[j - 1])
+                break
+            summation_term = summation_term + (lat[j] * lon[j + 1] - lat[j + 1] * lon[j])
+        area = summation_term / 2
+        s_long = s_lat = 0.0
+        for j in range(scan):
+            if lon[j] == 0:
+                s_long = s_long - (lon[j - 1] + lon[j]) * (lon[j - 1] * lat[j] - lon[j] * lat[j - 1])
+                s_lat = s_lat - (lat[j - 1] + lat[j]) * (lon[j - 1] * lat[j] - lon[j] * lat[j - 1])
+            else:
+                s_long = s_long + (lon[j] + lon[j + 1]) * (lon[j] * lat[j + 1] - lon[j + 1] * lat[j])
+                s_lat = s_lat + (lat[j] + lat[j + 1]) * (lon[j] * lat[j + 1] - lon[j + 1] * lat[j])
+        with np.errstate(all="ignore"):
+            clong[zid - 1] = np.float64(-s_long) / np.float64(6 * area)
+            clat[zid - 1] = np.float64(-s_lat) / np.float64(6 * area)
+    return clat, clong
+
+
+def processgeodata(path_to_json_data, path_to_data, csv_dataset_list, path_to_results):
+    """src/processgeodata.jl:3-181 -> (distance_matrix_km, number_zones).  GeoJSON parsing and the centroid sums are
+    host work (O(vertices)); the Z x Z distance matrix is computed and kept in HBM (DeviceArray).  Writes
+    zoneID_coordinates.csv (latitude, longitude; :168-177) into path_to_results when it is not None."""
+    with open(path_to_json_data, "r") as f:
+        doc = json.load(f)
+    number_zones, zones = geojson_vertex_lists(doc["features"])
+    clat, clong = polygon_centroids(number_zones, zones)
+    s, key = _sampler(number_zones)
+    s.set_distance_from_centroids(clat, clong)
+    if path_to_results is not None:
+        with open(os.path.join(path_to_results, "zoneID_coordinates.csv"), "w") as f:
+            f.write("latitude,longitude\n")
+            for i in range(number_zones):
+                f.write(f"{julia_float(clat[i])},{julia_float(clong[i])}\n")
+    h = DeviceArray("distance", number_zones)
+    _loaded[key]["dist_device"] = h.serial
+    return h, number_zones
+
+
+def createresultsdirectory(path_to_results_folder, city):
+    """src/createresultsdirectory.jl:3-17 (plain string concatenation, as there)."""
+    path_to_results = str(path_to_results_folder) + str(city)
+    if city not in os.listdir(path_to_results_folder):
+        os.mkdir(path_to_results)
+    return path_to_results
+
+
+def saveparameters(path_to_results, T, number_zones, cars_per_zone, C, e_drive, p_min, p_max, e_dest, A_drive):
+    """src/saveparameters.jl:3-25: one row of nine Float64 values under the reference's header."""
+    header = ["T (time steps)", "number_zones", "cars_per_zone", "C (number of cars)", "e_drive (model parameter 1)",
+              "p_min (model parameter 2)", "p_max (model parameter 3)", "e_dest (model parameter 4)", "A_drive"]
+    values = [T, number_zones, cars_per_zone, C, e_drive, p_min, p_max, e_dest, A_drive]
+    with open(os.path.join(path_to_results, "sampling_parameters.csv"), "w") as f:
+        f.write(",".join(header) + "\n")
+        f.write(",".join(julia_float(float(v)) for v in values) + "\n")
+
+
 # ------------------------------------------------------------------------------- tables
+def _use_dm(s, key, datamatrix, distance_matrix_km):
+    """Make `datamatrix` (+ the distance matrix when given) the arrays resident in the context."""
+    if isinstance(datamatrix, DeviceArray):
+        if _loaded[key].get("dm_device") != datamatrix.serial:
+            raise RuntimeError("this datamatrix is no longer resident: createdatamatrix() was called again for these zones")
+        if distance_matrix_km is not None and not isinstance(distance_matrix_km, DeviceArray):
+            raise TypeError("a device-resident datamatrix goes with the device-resident distance matrix of processgeodata()")
+        return
+    if isinstance(distance_matrix_km, DeviceArray):
+        distance_matrix_km = distance_matrix_km.numpy()
+    _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, distance_matrix_km))
+    _loaded[key].pop("dm_device", None)
+
+
 def createpdrive(datamatrix, distance_matrix_km, number_zones):
     """src/createpdrive.jl:3-38 -> p_drive (Z, T)."""
     s, key = _sampler(number_zones)
-    _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, distance_matrix_km))
+    _use_dm(s, key, datamatrix, distance_matrix_km)
     out = s.build_p_drive(params.p_min, params.p_max, params.e_drive, want=True)
     _loaded[key]["p_drive"] = _fingerprint(out)
     return out
@@ -85,7 +240,9 @@ def createpdestin(datamatrix, number_zones):
     """src/createpdestin.jl:3-50 -> p_dest (Z, Z, T).  Needs the distance matrix only through the
     datamatrix upload, so createpdrive (main.jl:82) is expected to have run first, as in main.jl."""
     s, key = _sampler(number_zones)
-    if _loaded[key].get("dm") != _fingerprint(datamatrix):
+    if isinstance(datamatrix, DeviceArray):
+        _use_dm(s, key, datamatrix, None)
+    elif _loaded[key].get("dm") != _fingerprint(datamatrix):
         raise RuntimeError("createpdestin: call createpdrive(datamatrix, distance_matrix_km, number_zones) "
                            "first, as main.jl:82-85 does (it uploads datamatrix and the distance matrix)")
     out = s.build_p_dest(params.e_dest, want=True)
@@ -126,7 +283,7 @@ def resampling(state_matrix, transition_matrix, C, number_zones, p_drive, p_dest
     _install(s, key, p_drive, p_dest)
     travel = datamatrix is not None and distance_matrix_km is not None
     if travel:
-        _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, distance_matrix_km))
+        _use_dm(s, key, datamatrix, distance_matrix_km)
     s.init_states(C, params.cars_per_zone)
     s.set_state(state_matrix[:, 0])
     r = s.resample(params.seed, travel=travel, want_state=True, want_trans=True)
@@ -174,18 +331,32 @@ def zone_hour_counts(number_zones, state_matrix, transition_matrix):
 
 
 def julia_float(x):
-    """Float64 -> text the way Julia prints it (shortest round-trip digits; 1.0e-5 style exponents)."""
+    """Float64 -> text the way Julia prints it: the shortest digits that round-trip, positional notation for
+    1e-5 < |x| < 1e6 (decimal exponent -4 .. 5), d.ddde[-]x otherwise (1.0e-5, 2.357e6), always with a fractional digit."""
+    from decimal import Decimal
+    x = float(x)
     if x != x:
         return "NaN"
     if x in (float("inf"), float("-inf")):
         return "Inf" if x > 0 else "-Inf"
-    r = repr(float(x))
-    if "e" in r:
-        mant, exp = r.split("e")
-        if "." not in mant:
-            mant += ".0"
-        return f"{mant}e{int(exp)}"
-    return r
+    if x == 0:
+        return "-0.0" if str(x).startswith("-") else "0.0"
+    sign, digits, exp = Decimal(repr(x)).as_tuple()        # repr: shortest round-trip digits
+    digits = list(digits)
+    while len(digits) > 1 and digits[-1] == 0:             # 2357000.0 -> digits 2357, exponent 3
+        digits.pop()
+        exp += 1
+    e10 = exp + len(digits) - 1                            # x = d.ddd * 10^e10
+    ds = "".join(map(str, digits))
+    if -5 < e10 < 6:
+        if e10 >= 0:
+            ip, fp = ds[:e10 + 1].ljust(e10 + 1, "0"), ds[e10 + 1:]
+            body = ip + "." + (fp or "0")
+        else:
+            body = "0." + "0" * (-e10 - 1) + ds
+    else:
+        body = ds[0] + "." + (ds[1:] or "0") + "e" + str(e10)
+    return ("-" if sign else "") + body
 
 
 def saveresults(number_zones, state_matrix, transition_matrix, path_to_results, data_set, C):
@@ -215,7 +386,7 @@ def run_dataset(datamatrix, distance_matrix_km, number_zones, travel=True):
     s, key = _sampler(number_zones)
     Z, T = int(number_zones), params.T
     C = Z * params.cars_per_zone
-    _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, distance_matrix_km))
+    _use_dm(s, key, datamatrix, distance_matrix_km)
     s.build_p_drive(params.p_min, params.p_max, params.e_drive, want=False)
     s.build_p_dest(params.e_dest, want=False)
     _loaded[key].pop("p_drive", None)

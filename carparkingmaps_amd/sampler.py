@@ -2,6 +2,7 @@
 reference's layout (Fortran order, 1-based zone ids).  One Sampler = one cpm_ctx = one GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -80,6 +81,36 @@ class Sampler:
         a = _f64(datamatrix, (self.Z, self.Z, self.T, 2))
         d = _f64(distance_matrix_km, (self.Z, self.Z))
         _lib.check(self._L.cpm_set_datamatrix(self._h, _vp(a), _vp(d)))
+
+    def createdatamatrix_rows(self, rawdata):
+        """rawdata: (n, 5) = the reference's rawdata[:,1:5]; builds the dense datamatrix in HBM."""
+        a = np.asfortranarray(rawdata, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 5:
+            raise ValueError(f"expected (n, 5) rows, got {a.shape}")
+        _lib.check(self._L.cpm_createdatamatrix_rows(self._h, int(a.shape[0]), _vp(a)))
+
+    def createdatamatrix_csv(self, path):
+        """Uber Movement CSV -> dense datamatrix in HBM (native parser); returns the number of data rows."""
+        n = C.c_int64(0)
+        _lib.check(self._L.cpm_createdatamatrix_csv(self._h, os.fsencode(path), C.byref(n)))
+        return int(n.value)
+
+    def get_datamatrix(self):
+        out = np.zeros((self.Z, self.Z, self.T, 2), dtype=np.float64, order="F")
+        _lib.check(self._L.cpm_get_datamatrix(self._h, _vp(out)))
+        return out
+
+    def set_distance_from_centroids(self, centroid_lat, centroid_long):
+        la = np.ascontiguousarray(centroid_lat, dtype=np.float64).reshape(-1)
+        lo = np.ascontiguousarray(centroid_long, dtype=np.float64).reshape(-1)
+        if la.shape != (self.Z,) or lo.shape != (self.Z,):
+            raise ValueError(f"expected {self.Z} centroids")
+        _lib.check(self._L.cpm_set_distance_from_centroids(self._h, _vp(la), _vp(lo)))
+
+    def get_distance(self):
+        out = np.zeros((self.Z, self.Z), dtype=np.float64, order="F")
+        _lib.check(self._L.cpm_get_distance(self._h, _vp(out)))
+        return out
 
     def build_p_drive(self, p_min, p_max, e_drive, want=True):
         out = np.zeros((self.Z, self.T), dtype=np.float64, order="F") if want else None
@@ -172,6 +203,17 @@ class Sampler:
         b = C.c_int64(0)
         _lib.check(self._L.cpm_algorithmic_bytes_per_hour(self._h, C.byref(b)))
         return int(b.value)
+
+
+def parse_uber_csv(path):
+    """The native CSV reader alone (host only): (n, 5) Fortran array = the reference's rawdata[:,1:5]."""
+    L = _lib.load()
+    n = C.c_int64(0)
+    _lib.check(L.cpm_parse_uber_csv(os.fsencode(path), C.byref(n), None, 0))
+    out = np.zeros((n.value, 5), dtype=np.float64, order="F")
+    if n.value:
+        _lib.check(L.cpm_parse_uber_csv(os.fsencode(path), C.byref(n), _vp(out), n.value))
+    return out
 
 
 def device_count():

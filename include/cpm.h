@@ -99,6 +99,27 @@ int32_t cpm_set_p_dest(cpm_ctx *ctx, const double *p_dest);
 /* uploads createdatamatrix's array (main.jl:79) and processgeodata's distance matrix
  * (main.jl:59); enables cpm_build_* and CPM_FLAG_TRAVEL */
 int32_t cpm_set_datamatrix(cpm_ctx *ctx, const double *datamatrix, const double *dist);
+/* createdatamatrix(path_to_csv_data, number_zones) (src/createdatamatrix.jl:3-27; main.jl:79) without the
+ * dense host array: the Z x Z x T x 2 datamatrix is built in HBM and stays there.
+ *   _rows: rawdata = the reference's rawdata[:,1:5] (n_rows x 5 Float64, column-major: sourceid, dstid,
+ *          hod, mean_travel_time, standard_deviation_travel_time) -- for a host that has parsed the CSV itself;
+ *   _csv : reads the Uber Movement CSV natively (header line, then 7 comma-separated numeric fields per
+ *          line of which the first five are used; memory-mapped, parsed by several threads).
+ * Zone id 0 -> Z on both endpoints, hod 0 -> 24 (:9-17); of several rows with the same (source, dest, hour)
+ * the last one wins (:21-22).  A row whose ids / hour are not integers in range -> CPM_ERR_ARG
+ * (reference: InexactError / BoundsError). */
+int32_t cpm_createdatamatrix_rows(cpm_ctx *ctx, int64_t n_rows, const double *rawdata);
+/* the CSV reader of _csv alone (host only, no device needed): *n_rows_out = data rows in the file; when
+ * rawdata_out is not NULL it receives the capacity_rows x 5 column-major matrix (first *n_rows_out rows filled) */
+int32_t cpm_parse_uber_csv(const char *path_to_csv_data, int64_t *n_rows_out, double *rawdata_out_or_null,
+                           int64_t capacity_rows);
+int32_t cpm_createdatamatrix_csv(cpm_ctx *ctx, const char *path_to_csv_data, int64_t *n_rows_out_or_null);
+int32_t cpm_get_datamatrix(cpm_ctx *ctx, double *datamatrix_out);
+/* the distance part of processgeodata (src/processgeodata.jl:148-166; main.jl:59): centroid_lat / centroid_long
+ * [Z] (degrees) -> distance_matrix_km [Z x Z] in HBM, 111.3 * sqrt(cos(mean lat * 0.01745)^2 * dlong^2 + dlat^2),
+ * diagonal 1 km.  (The GeoJSON parsing and the centroid sums are O(vertices) host work: host layer.) */
+int32_t cpm_set_distance_from_centroids(cpm_ctx *ctx, const double *centroid_lat, const double *centroid_long);
+int32_t cpm_get_distance(cpm_ctx *ctx, double *distance_matrix_km_out);
 /* createpdrive(datamatrix, distance_matrix_km, number_zones) with the script globals
  * p_min, p_max, e_drive passed explicitly (src/createpdrive.jl:3-38); installs the table and
  * optionally returns it */

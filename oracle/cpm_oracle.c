@@ -669,3 +669,106 @@ int orc_synth_datamatrix(int64_t Z, int64_t T, uint64_t table_seed, double densi
             }
     return ORC_OK;
 }
+
+/* =======================================================================================
+ * Data formats feeding the tables
+ * ======================================================================================= */
+
+/* src/createdatamatrix.jl:3-27 (after `rawdata = convert(Matrix, rawdata[:,1:5])`, :5) */
+int orc_createdatamatrix(const double *rawdata, int64_t n, int64_t Z, int64_t T, double *datamatrix)
+{
+    if (!datamatrix || Z < 1 || T < 1 || n < 0 || (n > 0 && !rawdata)) return ORC_ERR_BADARG;
+    memset(datamatrix, 0, sizeof(double) * (size_t)Z * (size_t)Z * (size_t)T * 2); /* :7 */
+    for (int64_t i = 0; i < n; ++i) {                                               /* :8 */
+        double r1 = rawdata[i], r2 = rawdata[n + i], r3 = rawdata[2 * n + i];
+        if (r1 == 0) r1 = (double)Z; /* :9-11 */
+        if (r2 == 0) r2 = (double)Z; /* :12-14 */
+        if (r3 == 0) r3 = 24;        /* :15-17 */
+        /* convert(Int64, x) (:18-20): InexactError unless integral; then BoundsError unless in range */
+        if (r1 != floor(r1) || r2 != floor(r2) || r3 != floor(r3)) return ORC_ERR_BADARG;
+        if (r1 < 1 || r1 > (double)Z || r2 < 1 || r2 > (double)Z || r3 < 1 || r3 > (double)T) return ORC_ERR_BADARG;
+        const size_t i1 = (size_t)r1 - 1, i2 = (size_t)r2 - 1, i3 = (size_t)r3 - 1;
+        const size_t cell = i1 + (size_t)Z * (i2 + (size_t)Z * i3);
+        datamatrix[cell] = rawdata[3 * n + i];                                   /* :21 */
+        datamatrix[cell + (size_t)Z * (size_t)Z * (size_t)T] = rawdata[4 * n + i]; /* :22 */
+    }
+    return ORC_OK;
+}
+
+/* src/processgeodata.jl:99-146.  Index j below is the reference's 1-based j; M(i,j) = matrix[i, j]. */
+int orc_centroids(double *lon, double *lat, int64_t Z, int64_t width, int64_t scan,
+                  double *centroid_lat, double *centroid_long, double *area)
+{
+    if (!lon || !lat || !centroid_lat || !centroid_long || !area || Z < 1 || scan + 1 > width) return ORC_ERR_BADARG;
+#define LON(i, j) lon[(size_t)(i) * (size_t)width + (size_t)((j)-1)]
+#define LAT(i, j) lat[(size_t)(i) * (size_t)width + (size_t)((j)-1)]
+    for (int64_t i = 0; i < Z; ++i) {
+        centroid_lat[i] = 0;
+        centroid_long[i] = 0;
+        area[i] = 0;
+    }
+    /* area of each polygon (:104-124) */
+    for (int64_t i = 0; i < Z; ++i) {
+        if (LON(i, 1) != 0) {
+            double summation_term = 0;
+            for (int64_t j = 1; j <= scan; ++j) {
+                if (LON(i, j) == 0) {
+                    if (j < 2) return ORC_ERR_BADARG; /* cannot happen: LON(i,1) != 0 */
+                    /* correction of summation term (:108) */
+                    summation_term = summation_term - (LAT(i, j - 1) * LON(i, j) - LAT(i, j) * LON(i, j - 1));
+                    /* addition of first vertex as last one (:111-112) */
+                    LON(i, j) = LON(i, 1);
+                    LAT(i, j) = LAT(i, 1);
+                    /* recalculation of last summation term (:115) */
+                    summation_term = summation_term + (LAT(i, j - 1) * LON(i, j) - LAT(i, j) * LON(i, j - 1));
+                    break;
+                } else {
+                    summation_term = summation_term + (LAT(i, j) * LON(i, j + 1) - LAT(i, j + 1) * LON(i, j)); /* :118 */
+                }
+            }
+            area[i] = summation_term / 2; /* :121 */
+        }
+    }
+    /* centroid coordinates (:127-146): no break in the zero branch */
+    for (int64_t i = 0; i < Z; ++i) {
+        if (LON(i, 1) != 0) {
+            double summation_long = 0, summation_lat = 0;
+            for (int64_t j = 1; j <= scan; ++j) {
+                if (LON(i, j) == 0) {
+                    if (j < 2) return ORC_ERR_BADARG;
+                    summation_long = summation_long - (LON(i, j - 1) + LON(i, j)) * (LON(i, j - 1) * LAT(i, j) - LON(i, j) * LAT(i, j - 1));
+                    summation_lat = summation_lat - (LAT(i, j - 1) + LAT(i, j)) * (LON(i, j - 1) * LAT(i, j) - LON(i, j) * LAT(i, j - 1));
+                } else {
+                    summation_long = summation_long + (LON(i, j) + LON(i, j + 1)) * (LON(i, j) * LAT(i, j + 1) - LON(i, j + 1) * LAT(i, j));
+                    summation_lat = summation_lat + (LAT(i, j) + LAT(i, j + 1)) * (LON(i, j) * LAT(i, j + 1) - LON(i, j + 1) * LAT(i, j));
+                }
+            }
+            centroid_long[i] = -summation_long / (6 * area[i]); /* :143 */
+            centroid_lat[i] = -summation_lat / (6 * area[i]);   /* :144 */
+        }
+    }
+#undef LON
+#undef LAT
+    return ORC_OK;
+}
+
+/* src/processgeodata.jl:148-166 */
+int orc_distance_matrix(const double *centroid_lat, const double *centroid_long, int64_t Z, double *dist)
+{
+    if (!centroid_lat || !centroid_long || !dist || Z < 1) return ORC_ERR_BADARG;
+    const double c_lat_long = 111.3;     /* :148 */
+    const double conv_deg_rad = 0.01745; /* :149 */
+    memset(dist, 0, sizeof(double) * (size_t)Z * (size_t)Z); /* :150 */
+    for (int64_t i = 0; i < Z - 1; ++i) {                    /* :151 i = 1:(number_zones-1) */
+        const double long1 = centroid_long[i], lat1 = centroid_lat[i];
+        for (int64_t j = i; j < Z; ++j) {                    /* :154 j = i:number_zones */
+            const double long2 = centroid_long[j], lat2 = centroid_lat[j];
+            const double c = cos((lat1 + lat2) / 2 * conv_deg_rad);
+            const double distance_km = c_lat_long * sqrt((c * c) * ((long1 - long2) * (long1 - long2)) + (lat1 - lat2) * (lat1 - lat2)); /* :157 */
+            dist[i + (size_t)Z * j] = distance_km; /* :158 */
+            dist[j + (size_t)Z * i] = distance_km; /* :159 */
+        }
+    }
+    for (int64_t i = 0; i < Z; ++i) dist[i + (size_t)Z * i] = 1; /* :164-166 */
+    return ORC_OK;
+}

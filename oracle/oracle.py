@@ -63,6 +63,9 @@ def lib():
     L.orc_synth_p_drive.argtypes = [i64, i64, u64, _f64p]
     L.orc_synth_p_dest_dense.argtypes = [i64, i64, u64, _f64p]
     L.orc_synth_datamatrix.argtypes = [i64, i64, u64, dbl, _f64p, _f64p]
+    L.orc_createdatamatrix.argtypes = [vp, i64, i64, i64, vp]
+    L.orc_centroids.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+    L.orc_distance_matrix.argtypes = [vp, vp, i64, vp]
     L.orc_max_threads.restype = C.c_int
     _LIB = L
     return L
@@ -207,6 +210,40 @@ def synth_datamatrix(Z, T, table_seed, density=0.0868):
     dist = np.zeros((Z, Z), dtype=np.float64, order="F")
     lib().orc_synth_datamatrix(Z, T, table_seed, density, dm, dist)
     return dm, dist
+
+
+def createdatamatrix(rawdata, Z, T=24):
+    """src/createdatamatrix.jl:3-27 on rawdata[:,1:5] (n x 5) -> datamatrix (Z, Z, T, 2)."""
+    raw = np.asfortranarray(rawdata, dtype=np.float64)
+    dm = np.zeros((Z, Z, T, 2), dtype=np.float64, order="F")
+    _check(lib().orc_createdatamatrix(_ptr(raw), raw.shape[0], Z, T, _ptr(dm)), "orc_createdatamatrix")
+    return dm
+
+
+def centroids(lon_rows, lat_rows, width=None, scan=10000):
+    """src/processgeodata.jl:99-146 on per-zone coordinate lists (zero-terminated inside a zeros(Z, width) matrix).
+    Returns (centroid_lat, centroid_long, area)."""
+    Z = len(lon_rows)
+    width = width or (scan + 2)
+    lon = np.zeros((Z, width), dtype=np.float64)
+    lat = np.zeros((Z, width), dtype=np.float64)
+    for i in range(Z):
+        k = len(lon_rows[i])
+        lon[i, :k] = lon_rows[i]
+        lat[i, :k] = lat_rows[i]
+    clat, clong, area = (np.zeros(Z) for _ in range(3))
+    _check(lib().orc_centroids(_ptr(lon), _ptr(lat), Z, width, scan, _ptr(clat), _ptr(clong), _ptr(area)), "orc_centroids")
+    return clat, clong, area
+
+
+def distance_matrix(centroid_lat, centroid_long):
+    """src/processgeodata.jl:148-166 -> distance_matrix_km (Z, Z)."""
+    la = np.ascontiguousarray(centroid_lat, dtype=np.float64)
+    lo = np.ascontiguousarray(centroid_long, dtype=np.float64)
+    Z = la.shape[0]
+    d = np.zeros((Z, Z), dtype=np.float64, order="F")
+    _check(lib().orc_distance_matrix(_ptr(la), _ptr(lo), Z, _ptr(d)), "orc_distance_matrix")
+    return d
 
 
 def max_threads():

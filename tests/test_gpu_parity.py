@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact for every
 integer result.  Run on the GPU box: python -m pytest tests -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -560,3 +562,116 @@ def test_high_word_table_rows_longer_than_a_power_of_two(cpm, O):
                                  [rng.integers(0, 2 ** 53, size=2000)]).astype(np.uint64)
             got, _ = s.debug_categorical(1, 1, k53)
             assert np.array_equal(got, _ref_categorical(cdf, k53)), Z
+
+
+# ------------------------------------------------------------------ data formats
+def _uber_rows(rng, Z, n, dup=0.02):
+    src = rng.integers(0, Z, n)          # 0 .. Z-1: id 0 is remapped to Z (src/createdatamatrix.jl:9-14)
+    dst = rng.integers(0, Z, n)
+    hod = rng.integers(0, 24, n)         # 0 .. 23: hod 0 -> 24 (:15-17)
+    k = int(n * dup)
+    if k:                                # repeated (source, dest, hour) keys: the last row must win (:21-22)
+        j = rng.integers(0, n, k)
+        i = rng.integers(0, n, k)
+        src[i], dst[i], hod[i] = src[j], dst[j], hod[j]
+    mean = np.round(300 + 2100 * rng.random(n), 2)
+    std = np.round(mean * (0.1 + 0.3 * rng.random(n)), 2)
+    return np.asfortranarray(np.column_stack([src, dst, hod, mean, std]).astype(np.float64))
+
+
+def test_createdatamatrix_rows_equals_the_reference_loop(cpm, O):
+    Z, T = 61, 24
+    rng = np.random.default_rng(21)
+    raw = _uber_rows(rng, Z, 40_000, dup=0.2)
+    want = O.createdatamatrix(raw, Z, T)
+    with cpm.Sampler(Z, T) as s:
+        s.createdatamatrix_rows(raw)
+        got = s.get_datamatrix()
+        assert np.array_equal(got, want)
+        s.createdatamatrix_rows(np.zeros((0, 5)))                       # no rows: all zeros (:7)
+        assert not s.get_datamatrix().any()
+        for bad in ([Z + 1, 1, 1, 1, 1], [1, 1, 25, 1, 1], [1.5, 1, 1, 1, 1], [-1, 1, 1, 1, 1]):
+            with pytest.raises(cpm.CpmError):
+                s.createdatamatrix_rows(np.array([[1, 1, 1, 5.0, 1.0], bad], dtype=float))
+
+
+def test_createdatamatrix_csv_to_tables_without_a_host_datamatrix(cpm, O, tmp_path):
+    """CSV text -> native reader -> dense datamatrix in HBM -> createpdrive / createpdestin on the device, against the
+    oracle fed with numpy's reading of the same file."""
+    Z, T = 47, 24
+    rng = np.random.default_rng(22)
+    raw = _uber_rows(rng, Z, 30_000, dup=0.05)
+    p = tmp_path / "city-2019-1-All-HourlyAggregate.csv"
+    with open(p, "w") as f:
+        f.write("sourceid,dstid,hod,mean_travel_time,standard_deviation_travel_time,geometric_mean_travel_time,"
+                "geometric_standard_deviation_travel_time\n")
+        for r in raw:
+            f.write(f"{int(r[0])},{int(r[1])},{int(r[2])},{float(r[3])!r},{float(r[4])!r},{float(r[3]) * 0.9!r},1.3\n")
+    lat = -38.5 + 1.5 * rng.random(Z)
+    lon = 144.0 + 2.0 * rng.random(Z)
+    dm = O.createdatamatrix(np.loadtxt(p, delimiter=",", skiprows=1, usecols=range(5)), Z, T)
+    dist = O.distance_matrix(lat, lon)
+    with cpm.Sampler(Z, T) as s:
+        assert s.createdatamatrix_csv(str(p)) == raw.shape[0]
+        assert np.array_equal(s.get_datamatrix(), dm)
+        s.set_distance_from_centroids(lat, lon)
+        got = s.get_distance()
+        np.testing.assert_allclose(got, dist, rtol=4e-16, atol=0)       # device cos vs glibc cos: <= 2 ulp of the result
+        assert np.array_equal(np.diag(got), np.ones(Z)) and np.array_equal(got, got.T)
+        p_drive = s.build_p_drive(0.1, 0.9, 0.5)
+        p_dest = s.build_p_dest(2)
+    # the tables from the device-built inputs equal the oracle's from its own (distance enters p_drive only through a
+    # division by values that agree to 2 ulp)
+    np.testing.assert_allclose(p_drive, O.createpdrive(dm, got, Z, T, 0.1, 0.9, 0.5), rtol=1e-15, atol=0)
+    np.testing.assert_allclose(p_dest, O.createpdestin(dm, Z, T, 2), rtol=1e-15, atol=0)
+
+
+def test_main_jl_flow_from_files(cpm, O, tmp_path):
+    """main.jl:51-109 for one city directory: GeoJSON + CSV in, result CSVs out, dense arrays device-resident throughout."""
+    import json
+    from carparkingmaps_amd import reference_api as R
+    Z, T, cpz = 24, 24, 50
+    rng = np.random.default_rng(23)
+    city = tmp_path / "cities" / "Testville"
+    city.mkdir(parents=True)
+    feats = []
+    for k in range(Z):                                        # MOVEMENT_IDs 0 .. Z-1: id 0 becomes zone Z
+        cx, cy = 144.0 + 0.1 * (k % 6), -38.0 + 0.1 * (k // 6)
+        ring = [[cx, cy], [cx + 0.08, cy], [cx + 0.08, cy + 0.07], [cx, cy + 0.07], [cx, cy]]
+        feats.append({"type": "Feature", "properties": {"MOVEMENT_ID": str(k)}, "geometry": {"type": "Polygon", "coordinates": [ring]}})
+    (city / "zz_testville.json").write_text(json.dumps({"type": "FeatureCollection", "features": feats}))
+    raw = _uber_rows(rng, Z, 6000, dup=0.05)
+    with open(city / "testville-2019-1.csv", "w") as f:
+        f.write("sourceid,dstid,hod,mean_travel_time,standard_deviation_travel_time,geometric_mean_travel_time,geometric_standard_deviation_travel_time\n")
+        for r in raw:
+            f.write(f"{int(r[0])},{int(r[1])},{int(r[2])},{float(r[3])!r},{float(r[4])!r},1,1\n")
+    results_root = str(tmp_path / "results") + "/"
+    os.mkdir(results_root)
+    R.release()
+    R.params.cars_per_zone, R.params.T = cpz, T
+    try:
+        dataset_list = sorted(os.listdir(city))               # main.jl:51-53: the GeoJSON sorts last
+        path_to_results = R.createresultsdirectory(results_root, "Testville")
+        dist, number_zones = R.processgeodata(str(city / dataset_list[-1]), str(city), dataset_list[:-1], path_to_results)
+        assert number_zones == Z
+        C = number_zones * cpz
+        datamatrix = R.createdatamatrix(str(city / dataset_list[0]), number_zones)
+        out = R.run_dataset(datamatrix, dist, number_zones, travel=True)
+        R.saveparameters(path_to_results, T, number_zones, cpz, C, R.params.e_drive, R.params.p_min, R.params.p_max, R.params.e_dest,
+                         out["A_drive_increment"])
+        # oracle on the same files
+        clat, clong = R.polygon_centroids(*R.geojson_vertex_lists(feats))
+        odist = O.distance_matrix(clat, clong)
+        odm = O.createdatamatrix(raw, Z, T)
+        np.testing.assert_allclose(dist.numpy(), odist, rtol=4e-16)
+        assert np.array_equal(datamatrix.numpy(), odm)
+        coords = np.loadtxt(os.path.join(path_to_results, "zoneID_coordinates.csv"), delimiter=",", skiprows=1)
+        assert np.array_equal(coords[:, 0], clat) and np.array_equal(coords[:, 1], clong)
+        p_drive = O.createpdrive(odm, dist.numpy(), Z, T, 0.1, 0.9, 0.5)
+        p_dest = O.createpdestin(odm, Z, T, 2)
+        ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, R.params.seed, _zone0(C, cpz))
+        assert np.array_equal(out["parking"], ref["parking"]) and np.array_equal(out["driving"], ref["driving"])
+        assert os.path.exists(os.path.join(path_to_results, "sampling_parameters.csv"))
+    finally:
+        R.release()
+        R.params.cars_per_zone, R.params.T = 1000, 24
