@@ -79,12 +79,13 @@ def pmc_traffic(kernel, Z, cars_per_gpu):
     MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  None when no run matches."""
     if Z != 4096 or cars_per_gpu != 4096000:
         return None, None
-    name = {0: "k_zone5_sample", 5: "k_zone5_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car"}[kernel]
-    for f in ("round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
+    name = {0: "k_zone6_sample", 5: "k_zone6_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car"}[kernel]
+    for f in ("round1_gen6_traffic.json", "round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             for k, v in json.load(open(path)).items():
-                if name in k and v.get("launches", 0) > 0:
+                # (the grouped form of k_zone6_sample: last template argument true; the plain form only runs the last hour)
+                if name in k and v.get("launches", 0) > 0 and (name != "k_zone6_sample" or ", true>(" in k):
                     return v["hbm_bytes_per_launch"], "profiles/" + f
     return None, None
 
@@ -202,6 +203,7 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(kernel_used, Z, count)
+        f64_bytes = Z * Z * 8 + Z * 8 + count * 8 + 2 * Z * 8  # SURVEY.md 8(d) with the reference's 8-byte rows
         out = {
             "metric": "car-steps/sec at Z=4,096, 1k cars/zone; 1/2/4/8 MI355X + %HBM roofline",
             "value": car_steps * args.steps / dt,
@@ -226,7 +228,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "hourly sampler launch", "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms)},
+                         "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "note": "algorithmic bytes use the element size the kernel streams (SURVEY.md 8d: substitute the variant's true "
+                                 "size): on the default grouped path a row is a pack of 4-byte CDF high words plus a 2-byte guide entry per "
+                                 "four destinations, not 8-byte f64; f64_equivalent prices the same launch at the reference's 8-byte rows",
+                         "f64_equivalent": {"algorithmic_bytes_per_launch": f64_bytes,
+                                            "achieved": f64_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                                            "frac": (f64_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else 0.0}},
             "full_pipeline": {"value": C * (2 * T - 1) / dt_full, "unit": "car-steps/s", "ms": dt_full * 1e3,
                               "what": "initializestates + 23-hour IVP + 24-hour resample (main.jl:88-95), 47 car-steps per car"},
         }

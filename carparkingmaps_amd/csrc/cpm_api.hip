@@ -718,6 +718,18 @@ int32_t cpm_set_distance_from_centroids(cpm_ctx *c, const double *centroid_lat, 
     return CPM_OK;
 }
 
+int32_t cpm_set_distance(cpm_ctx *c, const double *dist)
+{
+    CTX_TRY(c);
+    if (!dist) return fail(CPM_ERR_ARG, "null dist");
+    const size_t dbytes = sizeof(double) * c->Z * c->Z;
+    if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
+    HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_dist = true;
+    return CPM_OK;
+}
+
 int32_t cpm_get_distance(cpm_ctx *c, double *dist_out)
 {
     CTX_TRY(c);

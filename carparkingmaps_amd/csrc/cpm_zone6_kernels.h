@@ -251,8 +251,11 @@ __device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint
 // rank atomics in flight together.
 constexpr int kStage6 = 32;
 
+// Waves per SIMD the compiler must leave room for.  LDS admits 7 of these workgroups per CU at S4k (28 waves = 7 per SIMD);
+// asking for 8 squeezed the kernel into 94 SGPRs with 31 of them spilled to VGPR lanes (v_readlane / v_writelane on the
+// VALU this kernel is short of): measured 30.4 us at 8, 29.7 at 7, 28.2 at 6 (106 SGPRs, 7 waves per SIMD still fit).
 #ifndef CPM_WPS
-#define CPM_WPS 8
+#define CPM_WPS 6
 #endif
 template <bool TRAVEL, int BLOCK, int CPT, int NQ, bool GROUPED>
 __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zone6Args a)

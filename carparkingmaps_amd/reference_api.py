@@ -219,7 +219,7 @@ def _use_dm(s, key, datamatrix, distance_matrix_km):
         if _loaded[key].get("dm_device") != datamatrix.serial:
             raise RuntimeError("this datamatrix is no longer resident: createdatamatrix() was called again for these zones")
         if distance_matrix_km is not None and not isinstance(distance_matrix_km, DeviceArray):
-            raise TypeError("a device-resident datamatrix goes with the device-resident distance matrix of processgeodata()")
+            _ensure(key, s, "dist", distance_matrix_km, s.set_distance)  # a host distance matrix beside the device datamatrix
         return
     if isinstance(distance_matrix_km, DeviceArray):
         distance_matrix_km = distance_matrix_km.numpy()

@@ -107,6 +107,10 @@ class Sampler:
             raise ValueError(f"expected {self.Z} centroids")
         _lib.check(self._L.cpm_set_distance_from_centroids(self._h, _vp(la), _vp(lo)))
 
+    def set_distance(self, distance_matrix_km):
+        d = _f64(distance_matrix_km, (self.Z, self.Z))
+        _lib.check(self._L.cpm_set_distance(self._h, _vp(d)))
+
     def get_distance(self):
         out = np.zeros((self.Z, self.Z), dtype=np.float64, order="F")
         _lib.check(self._L.cpm_get_distance(self._h, _vp(out)))

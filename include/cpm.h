@@ -119,6 +119,8 @@ int32_t cpm_get_datamatrix(cpm_ctx *ctx, double *datamatrix_out);
  * [Z] (degrees) -> distance_matrix_km [Z x Z] in HBM, 111.3 * sqrt(cos(mean lat * 0.01745)^2 * dlong^2 + dlat^2),
  * diagonal 1 km.  (The GeoJSON parsing and the centroid sums are O(vertices) host work: host layer.) */
 int32_t cpm_set_distance_from_centroids(cpm_ctx *ctx, const double *centroid_lat, const double *centroid_long);
+/* uploads a distance matrix computed by the host (the reference's own processgeodata) next to a datamatrix built in HBM */
+int32_t cpm_set_distance(cpm_ctx *ctx, const double *distance_matrix_km);
 int32_t cpm_get_distance(cpm_ctx *ctx, double *distance_matrix_km_out);
 /* createpdrive(datamatrix, distance_matrix_km, number_zones) with the script globals
  * p_min, p_max, e_drive passed explicitly (src/createpdrive.jl:3-38); installs the table and

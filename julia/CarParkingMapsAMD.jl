@@ -50,7 +50,52 @@ end
 _seed() = isdefined(Main, :CPM_SEED) ? UInt64(Main.CPM_SEED) : UInt64(0x5EEDCA125)
 _dev() = isdefined(Main, :CPM_DEVICE) ? Int(Main.CPM_DEVICE) : 0
 
+# ---- device-resident datamatrix / distance matrix (src/createdatamatrix.jl:3-27, src/processgeodata.jl:148-166) ----
+# createdatamatrix() below reads the CSV natively and builds the Z x Z x T x 2 array in HBM; what it returns stands for
+# that array in the calls main.jl makes with it (createpdrive, createpdestin, resampling).
+struct DeviceArray
+    kind::Symbol
+    number_zones::Int
+end
+
+function createdatamatrix(path_to_csv_data, number_zones)
+    c = context(number_zones, Main.T, _dev())
+    n = Ref{Int64}(0)
+    _check(ccall((:cpm_createdatamatrix_csv, libcpm), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), c.h, path_to_csv_data, n))
+    DeviceArray(:datamatrix, Int(number_zones))
+end
+
+# the distance part of processgeodata on the device, from the centroids the reference computes (:99-146)
+function distance_from_centroids(centroid_lat::Vector{Float64}, centroid_long::Vector{Float64}, number_zones)
+    c = context(number_zones, Main.T, _dev())
+    GC.@preserve centroid_lat centroid_long begin
+        _check(ccall((:cpm_set_distance_from_centroids, libcpm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, centroid_lat, centroid_long))
+    end
+    DeviceArray(:distance, Int(number_zones))
+end
+
+function _use(c::Ctx, datamatrix, distance_matrix_km)
+    if datamatrix isa DeviceArray
+        if distance_matrix_km isa Matrix{Float64}      # the reference's processgeodata result beside the device datamatrix
+            GC.@preserve distance_matrix_km _check(ccall((:cpm_set_distance, libcpm), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.h, distance_matrix_km))
+        end
+    else
+        GC.@preserve datamatrix distance_matrix_km begin
+            _check(ccall((:cpm_set_datamatrix, libcpm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, datamatrix, distance_matrix_km))
+        end
+    end
+end
+
 # src/createpdrive.jl:3-38
+function createpdrive(datamatrix::DeviceArray, distance_matrix_km, number_zones)
+    c = context(number_zones, Main.T, _dev())
+    _use(c, datamatrix, distance_matrix_km)
+    p_drive = zeros(Float64, c.Z, c.T)
+    _check(ccall((:cpm_build_p_drive, libcpm), Cint, (Ptr{Cvoid}, Float64, Float64, Float64, Ptr{Float64}),
+                 c.h, Main.p_min, Main.p_max, Main.e_drive, p_drive))
+    p_drive
+end
+
 function createpdrive(datamatrix::Array{Float64,4}, distance_matrix_km::Matrix{Float64}, number_zones)
     c = context(number_zones, Main.T, _dev())
     GC.@preserve datamatrix distance_matrix_km begin
@@ -64,7 +109,7 @@ function createpdrive(datamatrix::Array{Float64,4}, distance_matrix_km::Matrix{F
 end
 
 # src/createpdestin.jl:3-50 (datamatrix was uploaded by createpdrive, main.jl:82 runs first)
-function createpdestin(datamatrix::Array{Float64,4}, number_zones)
+function createpdestin(datamatrix::Union{Array{Float64,4},DeviceArray}, number_zones)
     c = context(number_zones, Main.T, _dev())
     p_dest = zeros(Float64, c.Z, c.Z, c.T)
     _check(ccall((:cpm_build_p_dest, libcpm), Cint, (Ptr{Cvoid}, Float64, Cint, Ptr{Float64}),
@@ -108,10 +153,7 @@ end
 function resampling(state_matrix, transition_matrix, C, number_zones, p_drive, p_dest, datamatrix, distance_matrix_km)
     c = context(number_zones, Main.T, _dev())
     _install(c, p_drive, p_dest)
-    GC.@preserve datamatrix distance_matrix_km begin
-        _check(ccall((:cpm_set_datamatrix, libcpm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-                     c.h, datamatrix, distance_matrix_km))
-    end
+    _use(c, datamatrix, distance_matrix_km)
     _check(ccall((:cpm_init_states, libcpm), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Int64), c.h, C, Main.cars_per_zone, 0, C))
     zones = state_matrix[:, 1]
     _check(ccall((:cpm_set_state, libcpm), Cint, (Ptr{Cvoid}, Ptr{Int64}), c.h, zones))
@@ -146,6 +188,8 @@ initializestates(C) = CarParkingMapsAMD.initializestates(C)
 solveinitialvalueproblem(s, tr, pd, pde, C, Z) = CarParkingMapsAMD.solveinitialvalueproblem(s, tr, pd, pde, C, Z)
 resampling(s, tr, C, Z, pd, pde, dm, dist) = CarParkingMapsAMD.resampling(s, tr, C, Z, pd, pde, dm, dist)
 averagedrivingtime(C, A, tr) = CarParkingMapsAMD.averagedrivingtime(C, A, tr)
+# Optional (uncomment to keep the 6.4 GB datamatrix off the host): the CSV is then read by the library's own reader.
+# createdatamatrix(path_to_csv_data, number_zones) = CarParkingMapsAMD.createdatamatrix(path_to_csv_data, number_zones)
 
 # saveresults keeps the reference's CSV tail (src/saveresults.jl:23-42) and takes the counts from the device.
 function saveresults(number_zones, state_matrix, transition_matrix, path_to_results, data_set, C)
