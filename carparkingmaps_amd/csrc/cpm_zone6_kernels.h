@@ -468,7 +468,9 @@ __global__ __launch_bounds__(kPlace6Block) void k_zone6_place(const uint32_t *__
                                                               uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
                                                               unsigned long long *status)
 {
-    __shared__ uint32_t bins[kMaxZonesPerGroup6];
+    // bins: entries held in registers per destination zone, then this block's base inside the zone's bucket;
+    // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those
+    __shared__ uint32_t bins[kMaxZonesPerGroup6], tbins[kMaxZonesPerGroup6];
     const int tid = threadIdx.x;
     const int g = blockIdx.x % kGroups6, j = blockIdx.x / kGroups6;
     const int zg0 = g * zpg;
@@ -476,9 +478,12 @@ __global__ __launch_bounds__(kPlace6Block) void k_zone6_place(const uint32_t *__
     const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
     const int sub = tid >> 4, l16 = tid & 15;
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
-    for (int k = tid; k < kMaxZonesPerGroup6; k += kPlace6Block) bins[k] = 0;
+    for (int k = tid; k < kMaxZonesPerGroup6; k += kPlace6Block) {
+        bins[k] = 0;
+        tbins[k] = 0;
+    }
     if (zs0 >= zs1) return;  // (uniform per block)
-    uint32_t c[KRUNS], v[KRUNS][KDEEP];
+    uint32_t c[KRUNS], v[KRUNS][KDEEP], r[KRUNS][KDEEP];
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
         const int zs = zs0 + sub + k * kPlace6Seg;
@@ -490,38 +495,41 @@ __global__ __launch_bounds__(kPlace6Block) void k_zone6_place(const uint32_t *__
         for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
     }
     __syncthreads();
-    // pass 1: histogram of the destinations over the group's zones
+    // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
 #pragma unroll
-        for (int d = 0; d < KDEEP; ++d)
-            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) atomicAdd(&bins[v[k][d] >> idbits], 1u);
+        for (int d = 0; d < KDEEP; ++d) {
+            r[k][d] = 0;
+            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
+        }
     }
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
         const int zc = min(zs0 + sub + k * kPlace6Seg, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups6 + g;
-        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) atomicAdd(&bins[D[run * scap + i] >> idbits], 1u);
+        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) atomicAdd(&tbins[D[run * scap + i] >> idbits], 1u);
     }
     __syncthreads();
     if (tid < nzl) {  // ticket: this block's range inside each bucket of the group
-        const uint32_t cc = bins[tid];
+        const uint32_t cr = bins[tid], ct = tbins[tid];
         uint32_t base = 0;
-        if (cc) {
-            base = atomicAdd(&cnt_next[zg0 + tid], cc);
-            if (base + cc > cap) atomicOr(status, 2ull);
+        if (cr + ct) {
+            base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
+            if (base + cr + ct > cap) atomicOr(status, 2ull);
         }
         bins[tid] = base;
+        tbins[tid] = base + cr;
     }
     __syncthreads();
-    // pass 2: the ids move
+    // pass B: the ids move
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
 #pragma unroll
         for (int d = 0; d < KDEEP; ++d)
             if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) {
                 const uint32_t dl = v[k][d] >> idbits;
-                const uint32_t p = atomicAdd(&bins[dl], 1u);
+                const uint32_t p = bins[dl] + r[k][d];
                 if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = v[k][d] & idmask;
             }
     }
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(kPlace6Block) void k_zone6_place(const uint32_t *__
         for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) {
             const uint32_t w = D[run * scap + i];
             const uint32_t dl = w >> idbits;
-            const uint32_t p = atomicAdd(&bins[dl], 1u);
+            const uint32_t p = atomicAdd(&tbins[dl], 1u);
             if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
         }
     }
