@@ -1,6 +1,7 @@
 // cpm_zone6_kernels.h -- second generation of the grouped zone path (CPM_KERNEL_ZONE_GROUPED):
 //   * the row a workgroup stages is the HIGH WORD of the CDF row, 4 B per destination instead of 8, preceded by a
-//     GUIDE table (cut-point method) so that a draw costs ~2 LDS probes instead of a 12-level tree walk;
+//     GUIDE table (cut-point method) that brackets a draw's answer, so that a draw costs a few LDS probes instead of the
+//     12-level tree walk of the first generation;
 //   * the drivers of an origin zone go into FIXED-SIZE runs, one per destination group, so their position is
 //     known the moment their rank is (no scan, no second pass over the cars, no offsets for the placing
 //     kernel to fetch before it can fetch the runs).
@@ -22,9 +23,10 @@
 // hi[0] > 0 is accepted (cdf[0] > 0: the clamped answer), hi[0] == 0 is a tie.  Results are bit-identical
 // to the f64 search by construction; tests/test_gpu_parity.py drives the tie and out-of-range branches
 // through cpm_debug_categorical.
-// Guide.  guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G - 1 (u16; G = guide bits, 2^G >= Z by
-// default).  The answer of a draw lies in [guide[m], guide[m+1]], m = khi >> (32 - G): every j' < guide[m] has
-// hi[j'] < m << (32-G) <= khi, and hi[guide[m+1]] >= (m+1) << (32-G) > khi; a lower bound inside that bracket finds it.
+// Guide.  guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G (u16, clamped to Z - 1; G = guide bits = ceil(log2 Z) - 2,
+// a quarter of an entry per destination).  The answer of a draw lies in [guide[m], guide[m+1]], m = khi >> (32 - G): every
+// j' < guide[m] has hi[j'] < m << (32-G) <= khi, and hi[guide[m+1]] >= (m+1) << (32-G) > khi; a lower bound inside that bracket
+// finds it.  Draws with khi above the row's last high word never search (they take the exact fallback).
 // A row pack = [2^G + 8 u16 guide][Zq u32 hi] (Zq = Z rounded up to 32, padded with 0xFFFFFFFF), built next
 // to the CDF; HBM traffic of an hourly launch: Z * (2^G * 2 + Zq * 4) B of rows instead of Z * Zp * 8.
 //
@@ -131,8 +133,8 @@ struct Zone6Args {
     int64_t car_begin;
     uint64_t seed;
     unsigned long long *stamps;  // CPM_DIAGNOSTIC builds only: [Z][8] s_memtime stamps of wave 0 (tools/micro/sampler_bench.hip)
-    int abl;  // CPM_DIAGNOSTIC builds only (results WRONG): 1 no Philox, 2 no walk, 4 no emit stores, 8 no row load, 16 no ids load,
-              // 32 no per-car work at all (everybody stays), 64 no tree build, 128 no rank atomics
+    int abl;  // CPM_DIAGNOSTIC builds only (results WRONG): 1 no Philox, 2 no search, 16 synthetic ids, 32 no search / slot taking at all
+              // (everybody stays)
 };
 
 #ifdef CPM_DIAGNOSTIC
