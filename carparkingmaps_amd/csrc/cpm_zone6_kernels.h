@@ -251,7 +251,10 @@ __device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint
 // zone's REGION, not to its size, so they do not wait for the size); Philox runs while the pack is landing; after the
 // barrier the CPT cars of a thread search in lockstep and take their slots with one stayer ticket per wave and CPT
 // rank atomics in flight together.
-constexpr int kStage6 = 32;
+#ifndef CPM_STAGE6
+#define CPM_STAGE6 32
+#endif
+constexpr int kStage6 = CPM_STAGE6;
 
 // Waves per SIMD the compiler must leave room for.  LDS admits 7 of these workgroups per CU at S4k (28 waves = 7 per SIMD);
 // asking for 8 squeezed the kernel into 94 SGPRs with 31 of them spilled to VGPR lanes (v_readlane / v_writelane on the
