@@ -380,6 +380,7 @@ struct Zone5Work {
     uint32_t *Dq = nullptr;      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;    // [Z][kGroups] run lengths
     uint32_t scap = 0, idbits = 0, gshift6 = 0;
+    unsigned long long *tt_part = nullptr;  // [kTravelParts] partial travel-time sums (k_zone6_travel), kept zero between resamples
     int64_t n = 0;
     int Z = 0, T = 0;
 
@@ -390,10 +391,12 @@ struct Zone5Work {
         if (offz) (void)hipFree(offz);
         if (Dq) (void)hipFree(Dq);
         if (cntg) (void)hipFree(cntg);
+        if (tt_part) (void)hipFree(tt_part);
         D = nullptr;
         offz = nullptr;
         Dq = nullptr;
         cntg = nullptr;
+        tt_part = nullptr;
         n = 0;
     }
 
@@ -422,6 +425,10 @@ struct Zone5Work {
         gshift6 = zone6_gshift(Z);
         if (e == hipSuccess) e = hipMalloc(&Dq, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups * scap);
         if (e == hipSuccess) e = hipMalloc(&cntg, sizeof(uint32_t) * static_cast<size_t>(Z) * kGroups);
+        if (e == hipSuccess && !tt_part) {
+            e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
+            if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
+        }
         if (e != hipSuccess) release();
         return e;
     }
@@ -579,11 +586,24 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             b.seed = seed;
             b.abl = w.sampler.ablate;
             prof_begin(t);
+            // travel times: the last hour's sampler computes its own; for the other hours they are computed from the runs from the
+            // runs by k_zone6_travel, and the sampler runs in its faster form without them
             if (last_hour) zone6_launch<false>(b, travel, stream);
-            else zone6_launch<true>(b, travel, stream);
+            else zone6_launch<true>(b, false, stream);
             prof_end(t);
             if (!last_hour) {
-                zone6_launch_place(stream, w5.bpg ? w5.bpg : place_bpg(Z), w5.Dq, w5.cntg, 1 << w5.gshift6, Z, w.cap, w5.scap, w5.idbits, cnt_next, ids_next, status);
+                TravelArgs tr{};
+                tr.dm = d_dm;
+                tr.tt_part = w5.tt_part;
+                tr.T = T;
+                tr.t = t;
+                tr.gshift = static_cast<int>(w5.gshift6);
+                tr.step = step;
+                tr.car_begin = car_begin;
+                tr.seed = seed;
+                zone6_launch_place(stream, w5.bpg ? w5.bpg : place_bpg(Z), w5.Dq, w5.cntg, 1 << w5.gshift6, Z, w.cap, w5.scap, w5.idbits, cnt_next,
+                                   ids_next, status);
+                if (travel) hipLaunchKernelGGL(k_zone6_travel, dim3(Z), dim3(256), 0, stream, w5.Dq, w5.cntg, Z, w5.scap, w5.idbits, tr);
                 ids = ids_next;
                 cnt = cnt_next;
             }
@@ -615,6 +635,10 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             cnt = cnt_next;
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
+    }
+    if (v6 && travel && !ivp) {  // the partial sums of k_zone6_travel -> the sum word of the count tensor
+        hipLaunchKernelGGL(k_zone6_travel_finish, dim3(1), dim3(kTravelParts), 0, stream, w5.tt_part, tt_sum);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "travel-time sum");
     }
     if (ivp) {
         hipLaunchKernelGGL(k_zone5_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, w.cap, d_zone0_out);

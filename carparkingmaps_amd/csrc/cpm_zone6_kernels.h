@@ -467,6 +467,76 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
 constexpr int kPlace6Block = 1024;
 constexpr int kPlace6Seg = kPlace6Block / 16;
 
+// Travel times of an hour's drivers (src/resampling.jl:53-69), read back from the runs by a kernel of their own (one block per
+// origin zone, 8 lanes per run) instead of riding in the sampler, which they slow to a third of its occupancy (138 VGPRs).
+// The sum is an integer in 2^-16 s units: order-free, bit-exact.
+constexpr int kTravelParts = 256;
+
+struct TravelArgs {
+    const double *dm;
+    unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
+    int T, t, gshift;
+    uint32_t step;
+    int64_t car_begin;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ void zone6_travel_block(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
+                                                   uint32_t idbits, const TravelArgs &tr, int z)
+{
+    // The zone's drivers are dealt evenly over the threads whatever the run lengths are (popular destination groups
+    // hold most of them): driver i of the zone sits in run g with prefix[g] <= i < prefix[g+1].
+    __shared__ uint32_t prefix[kGroups6 + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const uint32_t c = (lane < kGroups6) ? min(cntg[static_cast<size_t>(z) * kGroups6 + lane], scap) : 0u;
+        uint32_t incl = c;
+        for (int o = 1; o < kGroups6; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane < kGroups6) prefix[lane + 1] = incl;
+        if (lane == 0) prefix[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = prefix[kGroups6];
+    const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    long long tt = 0;
+    for (uint32_t i = tid; i < total; i += blockDim.x) {
+        uint32_t g = 0;
+#pragma unroll
+        for (int step = kGroups6 / 2; step > 0; step >>= 1)
+            if (prefix[g + step] <= i) g += step;
+        const uint32_t w = D[(static_cast<size_t>(z) * kGroups6 + g) * scap + (i - prefix[g])];
+        const uint32_t dest = (g << tr.gshift) + (w >> idbits);
+        tt += travel_time_q16(tr.dm, Z, tr.T, tr.t, static_cast<uint32_t>(z), dest, tr.seed, static_cast<uint64_t>(tr.car_begin) + (w & idmask), tr.step);
+    }
+    // one global atomic per block, spread over kTravelParts words (atomics on ONE word are served one at a time at the memory
+    // side: four per block on the sum itself made this kernel 119 us per hour); k_zone6_travel_finish adds the parts up
+    __shared__ unsigned long long s_tt;
+    if (tid == 0) s_tt = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
+    if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
+    __syncthreads();
+    if (tid == 0 && s_tt) atomicAdd(&tr.tt_part[z % kTravelParts], s_tt);
+}
+
+__global__ __launch_bounds__(256) void k_zone6_travel_finish(unsigned long long *__restrict__ tt_part, unsigned long long *__restrict__ tt_sum)
+{
+    unsigned long long v = tt_part[threadIdx.x];
+    tt_part[threadIdx.x] = 0;  // ready for the next resample
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(tt_sum, v);
+}
+
+// one 256-thread block per origin zone
+__global__ __launch_bounds__(256) void k_zone6_travel(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
+                                                      uint32_t idbits, TravelArgs tr)
+{
+    zone6_travel_block(D, cntg, Z, scap, idbits, tr, blockIdx.x);
+}
+
 template <int KRUNS, int KDEEP>
 __global__ __launch_bounds__(kPlace6Block) void k_zone6_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg,
                                                               int zpg, int zps, int Z, uint32_t cap, uint32_t scap, uint32_t idbits,

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Resample with and without the travel-time pass (src/resampling.jl:53-78) on one GPU, Melbourne-shaped synthetic
+datamatrix (development tool)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import carparkingmaps_amd as cpm
+from oracle import oracle as O   # synthetic input generator only
+
+Z, T, cpz = 2357, 24, 1000
+C = Z * cpz
+dm, dist = O.synth_datamatrix(Z, T, 0x5EED7AB1E)
+with cpm.Sampler(Z, T) as s:
+    s.set_datamatrix(dm, dist)
+    s.build_p_drive(0.1, 0.9, 0.5, want=False)
+    s.build_p_dest(2, want=False)
+    s.init_states(C, cpz)
+    s.solve_ivp(0x5EEDCA125, want=False)
+    for travel in (False, True):
+        r = s.resample(0x5EEDCA125, travel=travel)
+        s.sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            r = s.resample(0x5EEDCA125, travel=travel)
+        dt = (time.perf_counter() - t0) / 10
+        print(f"travel={travel}: {dt * 1e3:.3f} ms per resample, {C * T / dt:.3e} car-steps/s, drivers {int(r['driving'].sum())}, sum_tt {r['sum_tt_q16'] / 65536:.1f} s")
