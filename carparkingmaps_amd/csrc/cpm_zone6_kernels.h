@@ -637,11 +637,15 @@ constexpr int kBlock6 = 256, kCpt6 = 4;  // measured at S4k: 512 x 2: 31 us, 256
 template <bool TRAVEL, bool GROUPED, int NQ>
 inline void zone6_launch_nq(const Zone6Args &a, size_t lds, hipStream_t stream)
 {
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_done = true;
+    if (lds > 48 * 1024) {  // LDS opt-in, once per device (contexts of several devices may live in one process)
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
     }
     hipLaunchKernelGGL((k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>), dim3(a.Z), dim3(kBlock6), lds, stream, a);
 }
