@@ -68,6 +68,7 @@ struct cpm_ctx {
     double *d_cdf = nullptr;     // [T][Z][Zp]
     uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_zone6_kernels.h)
     double *d_last = nullptr;    // [T][Z] row totals
+    long long *d_thr = nullptr;  // [T][Z] Bernoulli thresholds of p_drive (k_build_thr), rebuilt whenever p_drive changes
     int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
     double *d_dist = nullptr;    // [Z][Z]
@@ -145,6 +146,16 @@ int32_t check_err_flag(cpm_ctx *c, const char *what, int32_t code)
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         return fail(code, "%s", what);
     }
+    return CPM_OK;
+}
+
+// the integer Bernoulli thresholds of the p_drive now in d_pdrive (enqueued on the context's stream)
+int32_t update_thr(cpm_ctx *c)
+{
+    const int64_t n = c->Z * c->T;
+    if (!c->d_thr) HIP_TRY(hipMalloc(&c->d_thr, sizeof(long long) * static_cast<size_t>(n)));
+    hipLaunchKernelGGL(cpm::k_build_thr, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->d_pdrive, c->d_thr, n);
+    HIP_TRY(hipGetLastError());
     return CPM_OK;
 }
 
@@ -286,7 +297,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                          static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
                                          d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                         g_last_error, false, nullptr, c->d_hi, c->d_last, c->Zq);
+                                         g_last_error, false, nullptr, c->d_hi, c->d_last, c->Zq, c->d_thr);
         if (rc == CPM_OK && c->h_status && !c->status_pending) {
             if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                 hipEventRecord(c->status_ev, c->stream) == hipSuccess)
@@ -367,7 +378,7 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
         HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
         rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
-                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq);
+                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq, c->d_thr);
         if (rc != CPM_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost,
                                c->stream));
@@ -457,6 +468,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_cdf);
     dfree(c->d_hi);
     dfree(c->d_last);
+    dfree(c->d_thr);
     dfree(c->d_dm);
     dfree(c->d_dist);
     dfree(c->d_zone0);
@@ -543,6 +555,10 @@ int32_t cpm_set_p_drive(cpm_ctx *c, const double *p_drive)
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
     HIP_TRY(hipMemcpyAsync(c->d_pdrive, p_drive, bytes, hipMemcpyHostToDevice, c->stream));
+    {
+        int32_t rc_thr = update_thr(c);
+        if (rc_thr != CPM_OK) return rc_thr;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_pdrive = true;
     return CPM_OK;
@@ -753,10 +769,12 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
     hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64)), dim3(64), 0, c->stream, d_ms, c->d_pdrive,
                        static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);
     hipError_t e = hipGetLastError();
+    int32_t rc_thr = (e == hipSuccess) ? update_thr(c) : CPM_OK;
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dfree(d_ms);
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_drive: %s", hipGetErrorString(e));
+    if (rc_thr != CPM_OK) return rc_thr;
     c->have_pdrive = true;
     return CPM_OK;
 }
@@ -813,6 +831,10 @@ int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
     hipLaunchKernelGGL(cpm::k_synth_p_drive, dim3(nblk(c->Z * c->T, 256)), dim3(256), 0, c->stream, c->d_pdrive,
                        static_cast<int>(c->Z), static_cast<int>(c->T), table_seed);
     HIP_TRY(hipGetLastError());
+    {
+        int32_t rc_thr = update_thr(c);
+        if (rc_thr != CPM_OK) return rc_thr;
+    }
     c->have_pdrive = true;
     double *d_p = nullptr;
     HIP_TRY(hipMalloc(&d_p, sizeof(double) * c->Z * c->Z * c->T));

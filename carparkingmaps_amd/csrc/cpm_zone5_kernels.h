@@ -494,7 +494,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
                        int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
                        const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err,
                        bool ivp = false, uint32_t *d_zone0_out = nullptr, const uint32_t *d_hi = nullptr,
-                       const double *d_last = nullptr, int Zq = 0)
+                       const double *d_last = nullptr, int Zq = 0, const long long *d_thr = nullptr)
 {
     auto hip_fail = [&](hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);
@@ -559,6 +559,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             b.cnt = cnt;
             b.rp_t = d_hi + static_cast<size_t>(t) * Z * pack_row_words(Zq, pack_guide_bits(Z));
             b.last_t = d_last + static_cast<size_t>(t) * Z;
+            b.thr_t = d_thr ? d_thr + static_cast<size_t>(t) * Z : nullptr;
             b.pdrive_t = pd;
             b.cdf_t = cdf;
             b.dm = d_dm;

@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ c
     rp[row * pack_row_words(Zq, G) + pack_guide_words(G) + j] = h;
 }
 
+// thr[t][z] = bernoulli_threshold(p_drive[t][z]): the integer the sampler compares the 53-bit draw with (one scalar load per
+// workgroup instead of f64 arithmetic in every thread)
+__global__ __launch_bounds__(256) void k_build_thr(const double *__restrict__ pdrive, long long *__restrict__ thr, int64_t n)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) thr[i] = bernoulli_threshold(pdrive[i]);
+}
+
 // guide part: guide[m] = min(first j in [0, Z) with hi[j] >= m << (32 - G), Z - 1), m = 0 .. 2^G (entry 2^G and the pad: Z - 1)
 __global__ __launch_bounds__(256) void k_build_guide(uint32_t *__restrict__ rp, int Z, int Zq, int G, int64_t rows)
 {
@@ -121,6 +129,7 @@ struct Zone6Args {
     const uint32_t *cnt;      // [Z] their sizes
     const uint32_t *rp_t;     // [Z][RW] row packs of this hour: guide, then the high words of the CDF row
     const double *last_t;     // [Z] row totals (f64)
+    const long long *thr_t;   // [Z] Bernoulli thresholds floor(p_drive * 2^53) of this hour (bernoulli_threshold), or nullptr
     const double *pdrive_t, *cdf_t, *dm;
     uint32_t *ids_next;       // [Z*cap]       (grouped)
     uint32_t *cnt_next;       // [Z] stayers   (grouped; k_zone6_place adds the arrivals)
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
     const uint32_t n = min(n_raw, cap);
-    const long long thr = bernoulli_threshold(pd);
+    const long long thr = a.thr_t ? a.thr_t[z] : bernoulli_threshold(pd);
     if (tid == 0) {
         a.parking_t[z] = n;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         s_ndrive = 0;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
             if (!want[c]) dest[c] = z;
             else if (!ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
             if (drive[c]) {
-                ++nd;
+                if (!GROUPED) ++nd;  // (grouped: drivers = bucket size - stayers)
                 if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step);
             }
         }
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
         if (drive1) {
             if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest1[0], a.seed, car, a.step);
-            ++nd;
+            if (!GROUPED) ++nd;
         }
         if (GROUPED) {
             const unsigned long long m1 = __ballot(valid1 && !drive1);
@@ -432,8 +441,10 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         }
     }
     CPM_STAMP(a, z, 5);
-    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
-    if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
+    if (!GROUPED) {
+        for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+        if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
+    }
     if (TRAVEL) {
         for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
         if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         }
     }
     if (tid == 0) {
-        a.driving_t[z] = s_ndrive;
+        a.driving_t[z] = GROUPED ? n - s_nstay : s_ndrive;  // every car of the bucket either stays or drives
         if (GROUPED) a.cnt_next[z] = s_nstay;  // k_zone6_place adds the arrivals
         if (TRAVEL && s_tt) atomicAdd(a.tt_sum, s_tt);
     }

@@ -65,7 +65,7 @@ int main(int argc, char **argv)
     CK(hipMemset(d_counts, 0, sizeof(unsigned long long) * (2 * Z + 2)));
     Zone6Args a{};
     a.stamps = nullptr;
-    a.ids = d_ids; a.cnt = d_cnt; a.last_t = d_last; a.pdrive_t = d_pd; a.cdf_t = d_cdf; a.dm = nullptr;
+    a.ids = d_ids; a.cnt = d_cnt; a.thr_t = nullptr; a.last_t = d_last; a.pdrive_t = d_pd; a.cdf_t = d_cdf; a.dm = nullptr;
     a.ids_next = d_ids_next; a.cnt_next = d_cnt_next; a.D = d_D; a.cntg = d_cntg; a.rec_out = d_rec;
     a.parking_t = d_counts; a.driving_t = d_counts + Z; a.tt_sum = d_counts + 2 * Z; a.status = d_counts + 2 * Z + 1;
     a.Z = Z; a.Zp = Zp; a.Zq = Zq; a.G = G; a.T = T; a.t = 0;
