@@ -598,6 +598,19 @@ int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *d
     return CPM_OK;
 }
 
+// read_uber_csv with the C++ exceptions of its containers and threads turned into a message (nothing throws across the ABI)
+static std::string read_csv_noexcept(const char *path, cpm::CsvRows &rows)
+{
+    try {
+        const unsigned hw = std::thread::hardware_concurrency();
+        return cpm::read_uber_csv(path, static_cast<int>(std::min(32u, hw ? hw : 4u)), rows, nullptr);
+    } catch (const std::exception &e) {
+        return std::string(path) + ": " + e.what();
+    } catch (...) {
+        return std::string(path) + ": unknown failure while reading";
+    }
+}
+
 // createdatamatrix (src/createdatamatrix.jl:3-27) from rows already resident in d_raw (n x 5, column-major)
 static int32_t datamatrix_from_device_rows(cpm_ctx *c, const double *d_raw, int64_t n)
 {
@@ -641,8 +654,7 @@ int32_t cpm_parse_uber_csv(const char *path_to_csv_data, int64_t *n_rows_out, do
                             "." + std::to_string(st.st_mtim.tv_nsec);
     if (key != rows_key) {
         rows_key.clear();
-        const unsigned hw = std::thread::hardware_concurrency();
-        std::string err = cpm::read_uber_csv(path_to_csv_data, static_cast<int>(std::min(32u, hw ? hw : 4u)), rows, nullptr);
+        std::string err = read_csv_noexcept(path_to_csv_data, rows);
         if (!err.empty()) return fail(CPM_ERR_ARG, "parse_uber_csv: %s", err.c_str());
         rows_key = key;
     }
@@ -679,8 +691,7 @@ int32_t cpm_createdatamatrix_csv(cpm_ctx *c, const char *path_to_csv_data, int64
     CTX_TRY(c);
     if (!path_to_csv_data) return fail(CPM_ERR_ARG, "createdatamatrix: null path");
     cpm::CsvRows rows;
-    const unsigned hw = std::thread::hardware_concurrency();
-    std::string err = cpm::read_uber_csv(path_to_csv_data, static_cast<int>(std::min(32u, hw ? hw : 4u)), rows, nullptr);
+    std::string err = read_csv_noexcept(path_to_csv_data, rows);
     if (!err.empty()) return fail(CPM_ERR_ARG, "createdatamatrix: %s", err.c_str());
     if (n_rows_out) *n_rows_out = rows.n;
     if (rows.n >= (int64_t(1) << 32) - 1) return fail(CPM_ERR_ARG, "createdatamatrix: too many rows");
