@@ -589,8 +589,8 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
             prof_begin(t);
             // travel times: the last hour's sampler computes its own; for the other hours they are computed from the runs from the
             // runs by k_zone6_travel, and the sampler runs in its faster form without them
-            if (last_hour) zone6_launch<false>(b, travel, stream);
-            else zone6_launch<true>(b, false, stream);
+            if (last_hour) zone6_launch<false>(b, travel, (n + Z - 1) / Z, stream);
+            else zone6_launch<true>(b, false, (n + Z - 1) / Z, stream);
             prof_end(t);
             if (!last_hour) {
                 TravelArgs tr{};

@@ -182,8 +182,13 @@ __device__ __forceinline__ void pack_dma(uint32_t *lds, const uint32_t *pack, in
 template <int N, int NQ>
 __device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
 {
-    static_assert(N == 5 && NQ <= 63, "written for CPT = 4");
-    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]) : "n"(NQ) : "memory");
+    static_assert((N == 2 || N == 3 || N == 5) && NQ <= 63, "written for CPT = 1, 2, 4");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]) : "n"(NQ) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]) : "n"(NQ) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(id[0]), "+v"(id[1]) : "n"(NQ) : "memory");
 }
 
 // The f64 search of the other kernels, on the row where it lies in HBM (rare: ties and u above the row total).
@@ -643,9 +648,9 @@ inline void zone6_launch_place(hipStream_t stream, int bpg, const uint32_t *D, c
         hipLaunchKernelGGL((k_zone6_place<8, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
 }
 
-constexpr int kBlock6 = 256, kCpt6 = 4;  // measured at S4k: 512 x 2: 31 us, 256 x 4: 28, 128 x 8: 44
+constexpr int kBlock6 = 256;  // measured at S4k: 512 threads x 2 cars: 31 us, 256 x 4: 28, 128 x 8: 44
 
-template <bool TRAVEL, bool GROUPED, int NQ>
+template <bool TRAVEL, bool GROUPED, int CPT, int NQ>
 inline void zone6_launch_nq(const Zone6Args &a, size_t lds, hipStream_t stream)
 {
     if (lds > 48 * 1024) {  // LDS opt-in, once per device (contexts of several devices may live in one process)
@@ -653,37 +658,47 @@ inline void zone6_launch_nq(const Zone6Args &a, size_t lds, hipStream_t stream)
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone6_sample<TRAVEL, kBlock6, CPT, NQ, GROUPED>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_zone6_sample<TRAVEL, kBlock6, kCpt6, NQ, GROUPED>), dim3(a.Z), dim3(kBlock6), lds, stream, a);
+    hipLaunchKernelGGL((k_zone6_sample<TRAVEL, kBlock6, CPT, NQ, GROUPED>), dim3(a.Z), dim3(kBlock6), lds, stream, a);
 }
 
-template <bool TRAVEL, bool GROUPED>
-inline void zone6_launch_t(const Zone6Args &a, hipStream_t stream)
+template <bool TRAVEL, bool GROUPED, int CPT>
+inline void zone6_launch_c(const Zone6Args &a, hipStream_t stream)
 {
     const int words = pack_row_words(a.Zq, a.G);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kBlock6 - 1) / kBlock6;
-    if (need <= 1) zone6_launch_nq<TRAVEL, GROUPED, 1>(a, lds, stream);
-    else if (need <= 2) zone6_launch_nq<TRAVEL, GROUPED, 2>(a, lds, stream);
-    else if (need <= 3) zone6_launch_nq<TRAVEL, GROUPED, 3>(a, lds, stream);
-    else if (need <= 4) zone6_launch_nq<TRAVEL, GROUPED, 4>(a, lds, stream);
-    else if (need <= 5) zone6_launch_nq<TRAVEL, GROUPED, 5>(a, lds, stream);
-    else if (need <= 6) zone6_launch_nq<TRAVEL, GROUPED, 6>(a, lds, stream);
-    else if (need <= 8) zone6_launch_nq<TRAVEL, GROUPED, 8>(a, lds, stream);
-    else if (need <= 12) zone6_launch_nq<TRAVEL, GROUPED, 12>(a, lds, stream);
-    else if (need <= 20) zone6_launch_nq<TRAVEL, GROUPED, 20>(a, lds, stream);
-    else zone6_launch_nq<TRAVEL, GROUPED, 40>(a, lds, stream);
+    if (need <= 1) zone6_launch_nq<TRAVEL, GROUPED, CPT, 1>(a, lds, stream);
+    else if (need <= 2) zone6_launch_nq<TRAVEL, GROUPED, CPT, 2>(a, lds, stream);
+    else if (need <= 3) zone6_launch_nq<TRAVEL, GROUPED, CPT, 3>(a, lds, stream);
+    else if (need <= 4) zone6_launch_nq<TRAVEL, GROUPED, CPT, 4>(a, lds, stream);
+    else if (need <= 5) zone6_launch_nq<TRAVEL, GROUPED, CPT, 5>(a, lds, stream);
+    else if (need <= 6) zone6_launch_nq<TRAVEL, GROUPED, CPT, 6>(a, lds, stream);
+    else if (need <= 8) zone6_launch_nq<TRAVEL, GROUPED, CPT, 8>(a, lds, stream);
+    else if (need <= 12) zone6_launch_nq<TRAVEL, GROUPED, CPT, 12>(a, lds, stream);
+    else if (need <= 20) zone6_launch_nq<TRAVEL, GROUPED, CPT, 20>(a, lds, stream);
+    else zone6_launch_nq<TRAVEL, GROUPED, CPT, 40>(a, lds, stream);
+}
+
+// Cars per thread by the mean bucket size (cars of this GPU / zones): 256 x 4 slots for ~1000 cars per zone, 256 x 2 and 256 x 1
+// for smaller buckets (every slot runs Philox whether a car sits in it or not); larger buckets take the overflow rounds.
+template <bool TRAVEL, bool GROUPED>
+inline void zone6_launch_t(const Zone6Args &a, int64_t mean, hipStream_t stream)
+{
+    if (mean <= 224) zone6_launch_c<TRAVEL, GROUPED, 1>(a, stream);
+    else if (mean <= 560) zone6_launch_c<TRAVEL, GROUPED, 2>(a, stream);
+    else zone6_launch_c<TRAVEL, GROUPED, 4>(a, stream);
 }
 
 template <bool GROUPED>
-inline void zone6_launch(const Zone6Args &a, bool travel, hipStream_t stream)
+inline void zone6_launch(const Zone6Args &a, bool travel, int64_t mean, hipStream_t stream)
 {
-    if (travel) zone6_launch_t<true, GROUPED>(a, stream);
-    else zone6_launch_t<false, GROUPED>(a, stream);
+    if (travel) zone6_launch_t<true, GROUPED>(a, mean, stream);
+    else zone6_launch_t<false, GROUPED>(a, mean, stream);
 }
 
 // a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16

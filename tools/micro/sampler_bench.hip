@@ -83,7 +83,7 @@ int main(int argc, char **argv)
             int hour = 0;
             auto go = [&] {
                 a.rp_t = d_hi + static_cast<size_t>(hour++ % T) * Z * RW;
-                zone6_launch<true>(a, false, 0);
+                zone6_launch<true>(a, false, 1000, 0);
             };
             for (int k = 0; k < 5; ++k) go();
             CK(hipDeviceSynchronize());
