@@ -19,7 +19,7 @@ SYMBOLS = [
     "cpm_set_state", "cpm_get_state", "cpm_solve_ivp", "cpm_resample", "cpm_resample_dev",
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
     "cpm_debug_categorical", "cpm_createdatamatrix_rows", "cpm_createdatamatrix_csv", "cpm_get_datamatrix",
-    "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv", "cpm_set_distance",
+    "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv", "cpm_set_distance", "cpm_get_info",
 ]
 
 CPM_FLAG_TRAVEL = 1
@@ -102,6 +102,7 @@ def load():
     L.cpm_set_distance_from_centroids.argtypes = [vp, vp, vp]
     L.cpm_get_distance.argtypes = [vp, vp]
     L.cpm_set_distance.argtypes = [vp, vp]
+    L.cpm_get_info.argtypes = [vp, i32, C.POINTER(i64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("cpm_last_error",):

@@ -197,10 +197,21 @@ int pick_kernel(const cpm_ctx *c)
 {
     if (c->kernel != CPM_KERNEL_AUTO) return c->kernel;
     if (cpm::zone_path_fits(c->Zp) && c->n >= 32 * c->Z && c->n < (int64_t(1) << 32)) {
-        if (!c->grouped_overflowed && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z))) return CPM_KERNEL_ZONE_GROUPED;
+        if (!c->grouped_overflowed && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult)) return CPM_KERNEL_ZONE_GROUPED;
         return CPM_KERNEL_ZONE_LDS;
     }
     return CPM_KERNEL_CAR;
+}
+
+// After an overflow of the grouped layout: twice the bucket regions (and runs), while the problem still fits; the next
+// enqueue re-allocates the workspace.  false: no room to grow -- the caller falls back to the exact layout for good.
+bool grow_grouped(cpm_ctx *c)
+{
+    const int next = c->zw5.base.cap_mult * 2;
+    if (next > cpm::kMaxCapMult || !cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), next)) return false;
+    c->zw5.base.cap_mult = next;
+    c->zw5.base.buckets0_valid = false;
+    return true;
 }
 
 constexpr int kMaxProf = 8192;
@@ -286,13 +297,13 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
     if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
         c->status_pending = false;
-        if (*c->h_status != 0) c->grouped_overflowed = true;
+        if (*c->h_status != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
     }
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
     if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) {
-        if (!cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z)))
+        if (!cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
         int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                          static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
@@ -306,7 +317,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         return rc;
     }
     if (pick_kernel(c) == CPM_KERNEL_ZONE_STRIDED) {
-        if (!cpm::zone3_path_fits(c->Zp, c->n, static_cast<int>(c->Z)))
+        if (!cpm::zone3_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw3.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_STRIDED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
         return cpm::zone3_resample(c->zw3, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
                                    static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
@@ -348,6 +359,21 @@ int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
     return CPM_OK;
 }
 
+// The IVP on the grouped layout: new state beside the old one (d_ztmp), status word copied to pinned memory behind it.
+int32_t ivp_grouped(cpm_ctx *c, uint64_t seed)
+{
+    // the current state's buckets may be cached (zw5); everything else is stale once the IVP is committed
+    c->zw.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
+    int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
+                                     static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
+                                     c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq, c->d_thr);
+    if (rc != CPM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    return CPM_OK;
+}
+
 // Commit (or repeat on the exact layout) an IVP that was enqueued on the fixed-stride layout.  Called before
 // anything reads or replaces the car state.  Blocks until the IVP has drained.
 int32_t finish_ivp(cpm_ctx *c)
@@ -360,7 +386,22 @@ int32_t finish_ivp(cpm_ctx *c)
         HIP_TRY(cpm::zone5_commit_ivp(c->zw5, c->stream));
         return CPM_OK;
     }
-    c->grouped_overflowed = true;  // a bucket outgrew its region: d_zone0 is untouched, run the IVP again, exactly
+    // A bucket or a run outgrew its region: d_zone0 is untouched.  Run the IVP again with twice the regions while the problem
+    // still fits, else on the exact layout (and stay there).
+    while (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
+        int32_t rc = ivp_grouped(c, c->ivp_seed);
+        if (rc != CPM_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*c->h_ivp_status == 0) {
+            std::swap(c->d_zone0, c->d_ztmp);
+            HIP_TRY(cpm::zone5_commit_ivp(c->zw5, c->stream));
+            return CPM_OK;
+        }
+    }
+    c->grouped_overflowed = true;
+    c->zw.buckets0_valid = false;
+    c->zw3.buckets0_valid = false;
+    c->zw5.base.buckets0_valid = false;
     return ivp_exact(c, c->ivp_seed);
 }
 
@@ -371,17 +412,9 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     int32_t rc = finish_ivp(c);
     if (rc != CPM_OK) return rc;
     if (c->n == 0) return CPM_OK;
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z))) {
-        // the current state's buckets may be cached (zw5); everything else is stale once the IVP is committed
-        c->zw.buckets0_valid = false;
-        c->zw3.buckets0_valid = false;
-        HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
-        rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                 static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
-                                 c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq, c->d_thr);
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult)) {
+        rc = ivp_grouped(c, seed);
         if (rc != CPM_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost,
-                               c->stream));
         c->ivp_pending = true;
         c->ivp_seed = seed;
         return CPM_OK;
@@ -524,6 +557,21 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown option %d", option);
+    }
+}
+
+int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
+{
+    if (!c || !value_out) return fail(CPM_ERR_ARG, "null argument");
+    switch (what) {
+    case CPM_INFO_KERNEL:
+        *value_out = pick_kernel(c);
+        return CPM_OK;
+    case CPM_INFO_CAP_MULT:
+        *value_out = c->zw5.base.cap_mult;
+        return CPM_OK;
+    default:
+        return fail(CPM_ERR_ARG, "unknown info %d", what);
     }
 }
 
@@ -980,8 +1028,15 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         int64_t status = 0;
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (status != 0) {
-            c->grouped_overflowed = true;
+        // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
+        while (status != 0 && rc == CPM_OK && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
+            rc = resample_enqueue(c, seed, flags, c->d_counts);
+            if (rc != CPM_OK) break;
+            HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout
+            if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) c->grouped_overflowed = true;
             c->kernel = CPM_KERNEL_ZONE_LDS;
             rc = resample_enqueue(c, seed, flags, c->d_counts);
         }
@@ -1041,7 +1096,7 @@ int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
     // The second-generation grouped path streams the 4-byte high-word rows (Zq per row) instead of the f64 rows:
     // its true element size is substituted, as 8(d) prescribes for a variant with a different element size.
     const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zw5.v6 && c->d_hi &&
-                         cpm::zone6_path_fits(c->Zp, c->n, static_cast<int>(c->Z));
+                         cpm::zone6_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult);
     const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))) * 4 + c->Z * 8
                                  : c->Z * c->Z * 8;
     *bytes_out = rows + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;

@@ -137,6 +137,8 @@ struct Zone3Work {
     int64_t n = 0;
     int Z = 0, T = 0, nblk = 0, zones_per_blk = 0, nb0 = 0;
     uint32_t cap = 0;
+    int cap_mult = 4;        // bucket region = cap_mult x the mean bucket size; doubled by the context after an overflow (up to kMaxCapMult)
+    int cap_mult_alloc = 0;  // what the arrays below were sized for
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr, *dest = nullptr;  // [Z*cap]
     uint32_t *cnt0 = nullptr;                                                      // [Z] sizes of the cached initial buckets
     uint32_t *cnt = nullptr;                                                       // [T+1][Z] bucket sizes per hour
@@ -154,13 +156,14 @@ struct Zone3Work {
 
     hipError_t ensure(int64_t n_, int Z_, int T_, int cu_count)
     {
-        if (n_ == n && Z_ == Z && T_ == T && ids0) return hipSuccess;
+        if (n_ == n && Z_ == Z && T_ == T && ids0 && cap_mult_alloc == cap_mult) return hipSuccess;
         release();
         n = n_;
         Z = Z_;
         T = T_;
+        cap_mult_alloc = cap_mult;
         const int64_t mean = (n + Z - 1) / Z;
-        cap = static_cast<uint32_t>((std::max<int64_t>(4 * mean, 1024) + 63) / 64 * 64);
+        cap = static_cast<uint32_t>((std::max<int64_t>(cap_mult * mean, 1024) + 63) / 64 * 64);
         const int want = std::max(1, std::min(Z, 2 * cu_count));  // two 1024-thread blocks per CU overlap their phases
         zones_per_blk = std::min(kSort3MaxZones, (Z + want - 1) / want);
         while (static_cast<int64_t>(zones_per_blk) * ((cap + 1023) / 1024) > kSort3MaxPass && zones_per_blk > 1) --zones_per_blk;
@@ -184,12 +187,14 @@ struct Zone3Work {
 };
 
 // true when the fixed-stride layout is worth its memory: Z*cap slots x 4 arrays x 4 B
-inline bool zone3_path_fits(int Zp, int64_t n, int Z)
+constexpr int kMaxCapMult = 64;
+
+inline bool zone3_path_fits(int Zp, int64_t n, int Z, int cap_mult = 4)
 {
     if (!zone_path_fits(Zp) || n >= (int64_t(1) << 31)) return false;
     const int64_t mean = (n + Z - 1) / Z;
-    const int64_t cap = std::max<int64_t>(4 * mean, 1024);
-    return static_cast<int64_t>(Z) * cap * 16 <= (int64_t(8) << 30);  // <= 8 GiB of bucket arrays
+    const int64_t cap = std::max<int64_t>(cap_mult * mean, 1024);
+    return static_cast<int64_t>(Z) * cap * 16 <= (int64_t(cap_mult <= 4 ? 8 : 32) << 30);  // <= 8 GiB of bucket arrays (32 GiB once grown)
 }
 
 // The T-hour resample from the state in d_zone0 (left unchanged).  On bucket overflow bit 1 of the status

@@ -379,7 +379,7 @@ struct Zone5Work {
     bool v6 = true;              // CPM_OPT_GROUPED_GEN: 6 (default) or 5
     uint32_t *Dq = nullptr;      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;    // [Z][kGroups] run lengths
-    uint32_t scap = 0, idbits = 0, gshift6 = 0;
+    uint32_t scap = 0, idbits = 0, gshift6 = 0, cap_alloc = 0;
     unsigned long long *tt_part = nullptr;  // [kTravelParts] partial travel-time sums (k_zone6_travel), kept zero between resamples
     int64_t n = 0;
     int Z = 0, T = 0;
@@ -404,7 +404,7 @@ struct Zone5Work {
     {
         hipError_t e = base.ensure(n_, Z_, T_, cu_count);
         if (e != hipSuccess) return e;
-        if (n_ == n && Z_ == Z && T_ == T && D) return hipSuccess;
+        if (n_ == n && Z_ == Z && T_ == T && D && cap_alloc == base.cap) return hipSuccess;
         if (D) (void)hipFree(D);
         if (offz) (void)hipFree(offz);
         if (Dq) (void)hipFree(Dq);
@@ -420,6 +420,7 @@ struct Zone5Work {
         gmagic = (1u << 24) / static_cast<uint32_t>(zpg) + 1u;  // exact for dest < 2^14 (2^24 / zpg >= 2^15)
         e = hipMalloc(&D, sizeof(uint2) * static_cast<size_t>(Z) * base.cap);
         if (e == hipSuccess) e = hipMalloc(&offz, sizeof(uint32_t) * static_cast<size_t>(Z) * (kGroups + 1));
+        cap_alloc = base.cap;
         scap = zone6_scap(base.cap);
         idbits = zone6_idbits(Z);
         gshift6 = zone6_gshift(Z);
@@ -434,21 +435,21 @@ struct Zone5Work {
     }
 };
 
-inline bool zone5_path_fits(int Zp, int64_t n, int Z)
+inline bool zone5_path_fits(int Zp, int64_t n, int Z, int cap_mult = 4)
 {
     const int64_t mean = (n + Z - 1) / Z;
-    return zone3_path_fits(Zp, n, Z) && Z <= (1 << kRankShift) && (Z + kGroups - 1) / kGroups <= kMaxZonesPerGroup &&
+    return zone3_path_fits(Zp, n, Z, cap_mult) && Z <= (1 << kRankShift) && (Z + kGroups - 1) / kGroups <= kMaxZonesPerGroup &&
            (Z + place_bpg(Z) - 1) / place_bpg(Z) <= 8 * kPlaceSeg &&
-           n < (int64_t(1) << 30) && std::max<int64_t>(4 * mean, 1024) + 64 <= (int64_t(1) << (31 - kRankShift));  // rank field
+           n < (int64_t(1) << 30) && std::max<int64_t>(cap_mult * mean, 1024) + 64 <= (int64_t(1) << (31 - kRankShift));  // rank field
 }
 
 // second generation: also the packed id field and the run array (Z x 32 x scap x 4 B <= 16 GiB)
-inline bool zone6_path_fits(int Zp, int64_t n, int Z)
+inline bool zone6_path_fits(int Zp, int64_t n, int Z, int cap_mult = 4)
 {
-    if (!zone5_path_fits(Zp, n, Z) || !zone6_row_fits(Z)) return false;
+    if (!zone5_path_fits(Zp, n, Z, cap_mult) || !zone6_row_fits(Z)) return false;
     const int64_t mean = (n + Z - 1) / Z;
-    const uint32_t cap = static_cast<uint32_t>((std::max<int64_t>(4 * mean, 1024) + 63) / 64 * 64);
-    return n <= (int64_t(1) << zone6_idbits(Z)) && (1 << zone6_gshift(Z)) <= kMaxZonesPerGroup6 && static_cast<int64_t>(Z) * kGroups * zone6_scap(cap) * 4 <= (int64_t(16) << 30);
+    const uint32_t cap = static_cast<uint32_t>((std::max<int64_t>(cap_mult * mean, 1024) + 63) / 64 * 64);
+    return n <= (int64_t(1) << zone6_idbits(Z)) && (1 << zone6_gshift(Z)) <= kMaxZonesPerGroup6 && static_cast<int64_t>(Z) * kGroups * zone6_scap(cap) * 4 <= (int64_t(cap_mult <= 4 ? 16 : 48) << 30);
 }
 
 template <bool TRAVEL, int NP>
@@ -500,7 +501,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
         err = std::string(what) + ": " + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
     };
-    const bool v6 = w5.v6 && d_hi && d_last && zone6_path_fits(Zp, n, Z);
+    const bool v6 = w5.v6 && d_hi && d_last && zone6_path_fits(Zp, n, Z, w5.base.cap_mult);
     hipError_t e = w5.ensure(n, Z, T, cu_count);
     if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
     Zone3Work &w = w5.base;

@@ -57,6 +57,12 @@ class Sampler:
         """Raw cpm_set_option (tuning / A-B options of include/cpm.h)."""
         _lib.check(self._L.cpm_set_option(self._h, int(option), int(value)))
 
+    def get_info(self, what):
+        """cpm_get_info: 1 = kernel family AUTO resolves to now, 2 = bucket-region size in multiples of the mean bucket."""
+        v = C.c_int64(0)
+        _lib.check(self._L.cpm_get_info(self._h, int(what), C.byref(v)))
+        return int(v.value)
+
     def set_profile(self, on=True, stride=1):
         """hipEvents around every `stride`-th hourly sampler launch (0 / False: off)."""
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(stride) if on else 0))

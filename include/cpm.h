@@ -85,6 +85,13 @@ int32_t cpm_device_info(int32_t device_id, char *name, int32_t len, int32_t *cu_
 int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id);
 int32_t cpm_destroy(cpm_ctx *ctx);
 int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
+/* what the context would run now: CPM_INFO_KERNEL = the kernel family AUTO resolves to for the current tables / cars
+ * (CPM_KERNEL_*; changes to CPM_KERNEL_ZONE_LDS after an overflow that could not be absorbed), CPM_INFO_CAP_MULT = size of a
+ * zone's bucket region on the fixed-stride layouts in multiples of the mean bucket size (4; doubled, up to 64, each time a bucket
+ * or run outgrew it) */
+#define CPM_INFO_KERNEL 1
+#define CPM_INFO_CAP_MULT 2
+int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own */
 int32_t cpm_set_stream(cpm_ctx *ctx, void *hip_stream);
 int32_t cpm_sync(cpm_ctx *ctx);
@@ -165,9 +172,10 @@ int32_t cpm_resample(cpm_ctx *ctx, uint64_t seed, uint32_t flags, int64_t *parki
  * d_counts: DEVICE pointer to int64[2*T*Z + 2] = parking[T][Z] | driving[T][Z] | sum_tt_q16 |
  * status, zeroed and filled by the call (ready for one all-reduce).  status != 0 (after the
  * reduce: on any rank) means a fixed-stride zone kernel met a bucket that outgrew its region
- * (more than 4x the mean zone population in one zone); the counts are then invalid and the
- * caller repeats the step with CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR.  cpm_resample does this
- * by itself, and a context running CPM_KERNEL_AUTO uses the exact layout from then on. */
+ * (more than 4x the mean zone population in one zone) or a run that outgrew its slot; the counts
+ * are then invalid and the caller repeats the step: the context has doubled its regions when it
+ * next enqueues (while the problem fits, up to 64x the mean), after that a context running
+ * CPM_KERNEL_AUTO uses the exact layout.  cpm_resample and cpm_solve_ivp do all of this by themselves. */
 int32_t cpm_resample_dev(cpm_ctx *ctx, uint64_t seed, uint32_t flags, void *d_counts);
 int32_t cpm_solve_ivp_async(cpm_ctx *ctx, uint64_t seed);
 /* procedural synthetic tables of SURVEY.md 8(d), generated on device (bench inputs):

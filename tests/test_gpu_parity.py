@@ -698,3 +698,34 @@ def test_grouped_path_with_long_rows(cpm, O, Z, T, cpz):
         s.resample_dev(SIM_SEED, counts.data_ptr())
         s.sync()
         assert int(counts[-1].item()) == 0
+
+
+def test_overflow_is_absorbed_by_growing_the_bucket_regions(cpm, O):
+    """A popular zone that holds ~6x the mean: overflows the default regions (4x), fits after one doubling.  The blocking calls grow
+    and repeat by themselves; afterwards the grouped layout keeps running (no demotion to the exact layout) with clean status."""
+    import torch
+    Z, T, cpz = 64, 24, 800
+    C = Z * cpz
+    p_drive = np.full((Z, T), 0.5, order="F")
+    p_dest = np.zeros((Z, Z, T), order="F")
+    w = np.ones(Z)
+    w[7] = 7.0                       # zone 8 attracts 10 % of every hour's drivers: steady state 6.4x the mean population
+    p_dest[:, :, :] = (w / w.sum())[None, :, None]
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    assert 4 * cpz < ref["parking"].max() < 8 * cpz
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        assert s.get_info(1) == 5 and s.get_info(2) == 4
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+        assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
+        assert s.get_info(1) == 5 and s.get_info(2) == 8       # grew once, still the grouped layout
+        counts = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
+        s.resample_dev(SIM_SEED, counts.data_ptr())
+        s.sync()
+        assert int(counts[-1].item()) == 0
+        from carparkingmaps_amd.distributed import split_counts
+        pk, dr, _ = split_counts(counts, Z, T)
+        assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
