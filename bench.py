@@ -159,12 +159,20 @@ def main():
     # The fixed-stride zone kernels flag a bucket that outgrew its region in the status word (summed over
     # ranks by the all-reduce); the step is then invalid and the exact layout must be used instead.
     kernel_used = args.kernel
+    for _ in range(5):  # an overflowed step is flagged; the context doubles its bucket regions when it next enqueues
+        if int(ss.counts[-1].item()) == 0:
+            break
+        for _ in range(max(args.warmup, 1)):
+            ss.resample_allreduce(SIM_SEED)
+        barrier()
     if int(ss.counts[-1].item()) != 0:
         kernel_used = 2
         s.set_kernel(kernel_used)
         for _ in range(max(args.warmup, 1)):
             ss.resample_allreduce(SIM_SEED)
         barrier()
+    if kernel_used == 0:
+        kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
     # hipEvents on the launch stream around every 7th hourly sampler launch of the timed region (7 is
     # coprime to 24, so every hour of the day is sampled).  Bracketing every launch was measured to put
     # two ~5 us bubbles around each of them: 12 % of the step.
@@ -221,7 +229,8 @@ def main():
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
                        "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 4: "zone_strided",
-                                  5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " after overflow fallback"),
+                                  5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " (not the requested one: AUTO's choice or overflow fallback)"),
+                       "bucket_region_x_mean": s.get_info(2),
                        "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
                        "device": cpm.device_info(local_rank)["name"]},
