@@ -729,3 +729,41 @@ def test_overflow_is_absorbed_by_growing_the_bucket_regions(cpm, O):
         from carparkingmaps_amd.distributed import split_counts
         pk, dr, _ = split_counts(counts, Z, T)
         assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
+
+
+def test_examples_main_py_on_a_city_directory(cpm, O, tmp_path):
+    """examples/main.py (main.jl line for line) in both modes on a small synthetic city: same result files."""
+    import json
+    import subprocess
+    import sys
+    Z = 12
+    rng = np.random.default_rng(31)
+    city = tmp_path / "cities" / "Smallville"
+    city.mkdir(parents=True)
+    feats = []
+    for k in range(1, Z + 1):
+        cx, cy = 144.0 + 0.1 * (k % 4), -38.0 + 0.1 * (k // 4)
+        feats.append({"type": "Feature", "properties": {"MOVEMENT_ID": str(k)},
+                      "geometry": {"type": "Polygon", "coordinates": [[[cx, cy], [cx + 0.08, cy], [cx + 0.08, cy + 0.07], [cx, cy + 0.07], [cx, cy]]]}})
+    (city / "zz.json").write_text(json.dumps({"type": "FeatureCollection", "features": feats}))
+    raw = _uber_rows(rng, Z, 2500, dup=0.02)
+    raw[:, :2] += 1  # ids 1 .. Z
+    with open(city / "a.csv", "w") as f:
+        f.write("sourceid,dstid,hod,mean_travel_time,standard_deviation_travel_time,geometric_mean_travel_time,geometric_standard_deviation_travel_time\n")
+        for r in raw:
+            f.write(f"{int(r[0])},{int(r[1])},{int(r[2])},{float(r[3])!r},{float(r[4])!r},1,1\n")
+    outs = []
+    for mode in ([], ["--compat"]):
+        res = tmp_path / ("results" + ("_compat" if mode else ""))
+        res.mkdir()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call([sys.executable, os.path.join(root, "examples", "main.py"), str(tmp_path / "cities"), str(res), "--cars-per-zone", "40"] + mode)
+        d = res / "Smallville"
+        outs.append({n: (d / n).read_text() for n in sorted(os.listdir(d))})
+    assert set(outs[0]) == {"results_parkingdensities_a.csv", "results_trafficactivity_a.csv", "sampling_parameters.csv", "zoneID_coordinates.csv"}
+    for n in ("results_parkingdensities_a.csv", "results_trafficactivity_a.csv", "zoneID_coordinates.csv"):
+        assert outs[0][n] == outs[1][n], n
+    # A_drive: integer q16 sum on the device vs f64 sum of the host matrix: equal to ~1e-8 relative
+    a0 = float(outs[0]["sampling_parameters.csv"].splitlines()[1].split(",")[-1])
+    a1 = float(outs[1]["sampling_parameters.csv"].splitlines()[1].split(",")[-1])
+    assert abs(a0 - a1) <= 1e-7 * abs(a1)
