@@ -767,3 +767,26 @@ def test_examples_main_py_on_a_city_directory(cpm, O, tmp_path):
     a0 = float(outs[0]["sampling_parameters.csv"].splitlines()[1].split(",")[-1])
     a1 = float(outs[1]["sampling_parameters.csv"].splitlines()[1].split(",")[-1])
     assert abs(a0 - a1) <= 1e-7 * abs(a1)
+
+
+def test_contiguous_shard_of_an_8_gpu_run_starts_skewed(cpm, O):
+    """Rank 0 of 8 owns a contiguous car range: its cars start in an eighth of the zones, 8x the shard's mean bucket.  The default
+    regions (4x) overflow in the first IVP hour; the context grows them and stays on the grouped layout (what bench.py --gpus 8 does
+    on every rank).  Counts against the oracle run of the same shard."""
+    Z, T, world = 64, 24, 8
+    cpz = 300 * world
+    C = Z * cpz
+    count = C // world
+    p_drive, p_dest = _tables(O, Z, T)
+    zone0 = (np.arange(count, dtype=np.int64)) // cpz + 1          # rank 0: cars 0 .. count-1
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), count, SIM_SEED, zone0, car_offset=0)
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz, 0, count)
+        assert s.get_info(1) == 5 and s.get_info(2) == 4
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        assert s.get_info(1) == 5 and s.get_info(2) == 8            # grew, did not fall back
+        r = s.resample(SIM_SEED)
+        assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
+        assert (r["parking"].sum(axis=0) == count).all()
