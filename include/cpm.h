@@ -61,15 +61,16 @@ extern "C" {
 #define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
 #define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS; exact (packed) bucket layout, three launches per hour */
 /* 3 was an experimental persistent-workgroup form, removed (profiles/round1_notes.md) */
-#define CPM_KERNEL_ZONE_GROUPED 5 /* fixed-stride buckets; stayers kept by the sampler, drivers placed per destination group */
+#define CPM_KERNEL_ZONE_GROUPED 5 /* what AUTO runs: fixed-stride buckets, row packs (guide + 4-byte CDF high words, exact f64 fallback on ties)
+                                   * staged by LDS-DMA, stayers kept by the sampler, drivers placed per destination group; two launches per hour */
 #define CPM_KERNEL_ZONE_STRIDED 4 /* zone path with fixed-stride buckets: the counting sort is one kernel per hour */
 
 #define CPM_OPT_KERNEL 1
 #define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
                                    pair costs ~10 us of stream bubbles, so sample); 0: off */
-#define CPM_OPT_ZONE_BLOCK 3    /* tuning: workgroup size of the zone sampler (128..1024) */
-#define CPM_OPT_PLACE_SHAPE 4   /* tuning: grouped path, blocks per destination group * 10 + pairs per lane (82, 81, 162, 161) */
-#define CPM_OPT_GROUPED_GEN 5   /* A/B: 6 (default) = high-word rows + fixed-size runs, 5 = first generation (f64 rows) */
+#define CPM_OPT_ZONE_BLOCK 3    /* A/B, exact layout only: 0 = tree-layout sampler (default); 256 / 512 = first-generation sorted-row sampler */
+#define CPM_OPT_PLACE_SHAPE 4   /* tuning: grouped path, blocks per destination group * 10 + entries per lane (82, 81, 162, 161); 0 = by zone count */
+#define CPM_OPT_GROUPED_GEN 5   /* A/B: 6 (default) = row packs + fixed-size runs, 5 = first generation of the grouped path (f64 rows, offsets) */
 #define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;
