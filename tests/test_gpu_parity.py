@@ -790,3 +790,43 @@ def test_contiguous_shard_of_an_8_gpu_run_starts_skewed(cpm, O):
         r = s.resample(SIM_SEED)
         assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
         assert (r["parking"].sum(axis=0) == count).all()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_small_configurations(cpm, O, seed):
+    """Random small problems through the grouped path and AUTO: odd zone counts, T from 1 to 24, one car to hundreds per zone,
+    sparse rows, all-zero rows, single-destination rows, unreachable zones, p_drive of 0 / 1 / NaN.  Bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    Z = int(rng.integers(2, 150))
+    T = int(rng.choice([1, 2, 5, 24]))
+    cpz = int(rng.choice([1, 2, 7, 40, 120, 300]))
+    C = Z * cpz
+    p_drive = np.asfortranarray(rng.random((Z, T)))
+    p_drive[rng.random((Z, T)) < 0.05] = 0.0
+    p_drive[rng.random((Z, T)) < 0.05] = 1.0
+    p_drive[rng.random((Z, T)) < 0.02] = np.nan                      # never drives (Appendix A-3)
+    w = rng.random((Z, Z, T)) ** 3
+    w[rng.random((Z, Z, T)) < float(rng.choice([0.0, 0.5, 0.9]))] = 0.0  # sparse rows
+    w[:, rng.random(Z) < 0.1, :] = 0.0                               # zones nobody drives to
+    for o in np.flatnonzero(rng.random(Z) < 0.1):                    # single-destination rows
+        w[o, :, :] = 0.0
+        w[o, int(rng.integers(0, Z)), :] = 1.0
+    w[rng.random(Z) < 0.1, :, :] = 0.0                               # all-zero rows: destination = origin, counted as driving
+    p_dest = np.zeros((Z, Z, T), order="F")
+    for t in range(T):
+        for o in range(Z):
+            tot = 0.0
+            for v in w[o, :, t]:
+                tot += v                                             # the sequential sum of src/createpdestin.jl:31-35
+            if tot > 0:
+                p_dest[o, :, t] = w[o, :, t] / tot
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED + seed, _zone0(C, cpz))
+    for kernel in (5, 0):
+        with cpm.Sampler(Z, T) as s:
+            s.set_kernel(kernel)
+            s.set_p_drive(p_drive)
+            s.set_p_dest(p_dest)
+            s.init_states(C, cpz)
+            assert np.array_equal(s.solve_ivp(SIM_SEED + seed), ref["zone0"]), (kernel, Z, T, cpz)
+            r = s.resample(SIM_SEED + seed)
+            assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (kernel, Z, T, cpz)
