@@ -55,6 +55,7 @@ __global__ void k_zones_to_i64(int64_t *zones1, const uint32_t *zone0, int64_t n
 // coalesced too.  Also validates the table (NaN / negative entries -> *err).
 // ---------------------------------------------------------------------------------------
 constexpr int kCdfTile = 64;
+constexpr int kCdfBatch = 32;
 
 __global__ __launch_bounds__(kCdfTile) void k_build_cdf(const double *__restrict__ p, double *__restrict__ cdf,
                                                         int Z, int Zp, int *err)
@@ -70,19 +71,28 @@ __global__ __launch_bounds__(kCdfTile) void k_build_cdf(const double *__restrict
     bool bad = false;
     for (int d0 = 0; d0 < Zp; d0 += kCdfTile) {
         if (o < Z) {
-#pragma unroll 8
-            for (int j = 0; j < kCdfTile; ++j) {
-                int d = d0 + j;
-                double v;
-                if (d < Z) {
-                    double x = src[static_cast<size_t>(d) * Z];
-                    bad |= !(x >= 0.0);
-                    run = run + x;
-                    v = run;
-                } else {
-                    v = __builtin_huge_val();
+            // the running sum is sequential (src/resampling.jl:39), the loads are not: kCdfBatch of them in flight per lane
+#pragma unroll
+            for (int j0 = 0; j0 < kCdfTile; j0 += kCdfBatch) {
+                double x[kCdfBatch];
+#pragma unroll
+                for (int u = 0; u < kCdfBatch; ++u) {
+                    const int d = d0 + j0 + u;
+                    x[u] = (d < Z) ? src[static_cast<size_t>(d) * Z] : 0.0;
                 }
-                tile[lane][j] = v;
+#pragma unroll
+                for (int u = 0; u < kCdfBatch; ++u) {
+                    const int d = d0 + j0 + u;
+                    double v;
+                    if (d < Z) {
+                        bad |= !(x[u] >= 0.0);
+                        run = run + x[u];
+                        v = run;
+                    } else {
+                        v = __builtin_huge_val();
+                    }
+                    tile[lane][j0 + u] = v;
+                }
             }
         }
         __syncthreads();

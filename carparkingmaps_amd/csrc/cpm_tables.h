@@ -9,6 +9,8 @@
 
 namespace cpm {
 
+constexpr int kTabBatch = 16;  // independent loads a lane keeps in flight in the sequential table sums
+
 // Julia's maximum/minimum propagate NaN (Appendix A-3); fmax/fmin would not.
 __device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
 __device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
@@ -21,12 +23,30 @@ __global__ void k_pdrive_mean(const double *__restrict__ dm, const double *__res
     int t = blockIdx.y;
     if (i >= Z) return;
     const double *src = dm + static_cast<size_t>(t) * Z * Z + i;
+    const double *dst = dist + i;
     double s = 0.0;
     long long counter = 0;
-    for (int j = 0; j < Z; ++j) {
+    // The sum runs left to right (the reference's order) but the loads do not depend on it: kTabBatch of them are requested
+    // together, so that a lane has kTabBatch x 2 loads in flight instead of one round trip per destination.
+    int j = 0;
+    for (; j + kTabBatch <= Z; j += kTabBatch) {
+        double m[kTabBatch], d[kTabBatch];
+#pragma unroll
+        for (int u = 0; u < kTabBatch; ++u) {
+            m[u] = src[static_cast<size_t>(j + u) * Z];
+            d[u] = dst[static_cast<size_t>(j + u) * Z];
+        }
+#pragma unroll
+        for (int u = 0; u < kTabBatch; ++u)
+            if (m[u] != 0) {
+                s = s + m[u] / d[u];
+                counter += 1;
+            }
+    }
+    for (; j < Z; ++j) {
         double m = src[static_cast<size_t>(j) * Z];
         if (m != 0) {
-            s = s + m / dist[i + static_cast<size_t>(j) * Z];
+            s = s + m / dst[static_cast<size_t>(j) * Z];
             counter += 1;
         }
     }
@@ -114,9 +134,26 @@ __global__ void k_pdest_normalise(double *__restrict__ p, int Z)
     if (i >= Z) return;
     double *row = p + static_cast<size_t>(t) * Z * Z + i;
     double nf = 0.0;
-    for (int j = 0; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
-    if (nf > 0)
-        for (int j = 0; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
+    int j = 0;
+    for (; j + kTabBatch <= Z; j += kTabBatch) {  // loads in batches, sum in order (see k_pdrive_mean)
+        double v[kTabBatch];
+#pragma unroll
+        for (int u = 0; u < kTabBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
+#pragma unroll
+        for (int u = 0; u < kTabBatch; ++u) nf = nf + v[u];
+    }
+    for (; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
+    if (nf > 0) {
+        j = 0;
+        for (; j + kTabBatch <= Z; j += kTabBatch) {
+            double v[kTabBatch];
+#pragma unroll
+            for (int u = 0; u < kTabBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
+#pragma unroll
+            for (int u = 0; u < kTabBatch; ++u) row[static_cast<size_t>(j + u) * Z] = v[u] / nf;
+        }
+        for (; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
+    }
 }
 
 }  // namespace cpm
