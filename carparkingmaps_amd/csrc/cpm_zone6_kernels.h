@@ -518,14 +518,43 @@ __device__ __forceinline__ void zone6_travel_block(const uint32_t *__restrict__ 
     const uint32_t total = prefix[kGroups6];
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
     long long tt = 0;
-    for (uint32_t i = tid; i < total; i += blockDim.x) {
-        uint32_t g = 0;
+    // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
+    // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
+    constexpr int kTravelBatch = 4;
+    const size_t sd_off = static_cast<size_t>(Z) * Z * tr.T;
+    for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
+        uint32_t w[kTravelBatch], dest[kTravelBatch];
+        bool live[kTravelBatch];
 #pragma unroll
-        for (int step = kGroups6 / 2; step > 0; step >>= 1)
-            if (prefix[g + step] <= i) g += step;
-        const uint32_t w = D[(static_cast<size_t>(z) * kGroups6 + g) * scap + (i - prefix[g])];
-        const uint32_t dest = (g << tr.gshift) + (w >> idbits);
-        tt += travel_time_q16(tr.dm, Z, tr.T, tr.t, static_cast<uint32_t>(z), dest, tr.seed, static_cast<uint64_t>(tr.car_begin) + (w & idmask), tr.step);
+        for (int u = 0; u < kTravelBatch; ++u) {
+            const uint32_t i = i0 + u * blockDim.x;
+            live[u] = i < total;
+            uint32_t g = 0;
+#pragma unroll
+            for (int step = kGroups6 / 2; step > 0; step >>= 1)
+                if (prefix[g + step] <= i) g += step;
+            g = live[u] ? g : 0u;
+            w[u] = live[u] ? D[(static_cast<size_t>(z) * kGroups6 + g) * scap + (i - prefix[g])] : 0u;
+            dest[u] = (g << tr.gshift) + (w[u] >> idbits);
+        }
+        double mean[kTravelBatch], sd[kTravelBatch];
+#pragma unroll
+        for (int u = 0; u < kTravelBatch; ++u) {
+            const bool moving = live[u] && dest[u] != static_cast<uint32_t>(z);
+            const size_t cell = static_cast<size_t>(z) + static_cast<size_t>(Z) * (dest[u] + static_cast<size_t>(Z) * tr.t);
+            mean[u] = moving ? tr.dm[cell] : 0.0;
+            sd[u] = moving ? tr.dm[cell + sd_off] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kTravelBatch; ++u) {
+            if (!live[u]) continue;
+            if (dest[u] == static_cast<uint32_t>(z)) {  // same zone: 300 s (src/resampling.jl:58-60)
+                tt += q16(300.0);
+            } else {
+                const double s1 = (sd[u] == 0) ? 0.1 * mean[u] : sd[u];  // :65-67
+                tt += q16(truncnormal_pm10(tr.seed, static_cast<uint64_t>(tr.car_begin) + (w[u] & idmask), tr.step, 1, mean[u], s1));
+            }
+        }
     }
     // one global atomic per block, spread over kTravelParts words (atomics on ONE word are served one at a time at the memory
     // side: four per block on the sum itself made this kernel 119 us per hour); k_zone6_travel_finish adds the parts up
