@@ -6,14 +6,14 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import carparkingmaps_amd as cpm
-from oracle import oracle as O   # synthetic input generator only
+import _synth
 
 Z, T, cpz = 4096, 24, 1000
 C = Z * cpz
-p_drive = O.synth_p_drive(Z, T, 0x5EED7AB1E)
-p_dest = O.synth_p_dest_dense(Z, T, 0x5EED7AB1E)
+p_drive, p_dest = _synth.dense_tables(Z, T)
 with cpm.Sampler(Z, T) as s:
     s.set_p_drive(p_drive)
     s.set_p_dest(p_dest)  # first call: allocations

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ingest measurements on one GPU (development tool): Uber-Movement-shaped CSV -> datamatrix in HBM
-(cpm_createdatamatrix_csv: native parse + upload + two scatter passes), centroids -> distance matrix, and the oracle's
-reference loop beside them.  Melbourne shape by default (Z = 2,357; the real files hold ~11.6 M rows)."""
+(cpm_createdatamatrix_csv: native parse + upload + two scatter passes), centroids -> distance matrix.
+Melbourne shape by default (Z = 2,357; the real files hold ~11.6 M rows)."""
 import argparse
 import os
 import sys
@@ -16,7 +16,6 @@ from carparkingmaps_amd.sampler import parse_uber_csv
 ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=2357)
 ap.add_argument("--rows", type=int, default=4_000_000)
-ap.add_argument("--oracle", action="store_true")
 args = ap.parse_args()
 Z, n = args.zones, args.rows
 rng = np.random.default_rng(1)
@@ -48,9 +47,3 @@ with cpm.Sampler(Z, 24) as s:
     t0 = time.perf_counter()
     s.set_distance_from_centroids(lat, lon)
     print(f"distance matrix {Z} x {Z}: {1e3 * (time.perf_counter() - t0):.2f} ms")
-    if args.oracle:
-        from oracle import oracle as O
-        t0 = time.perf_counter()
-        dm = O.createdatamatrix(rows, Z, 24)
-        t_o = time.perf_counter() - t0
-        print(f"oracle (the reference's row loop, one core, after parsing): {t_o * 1e3:.0f} ms; equal to the device result: {np.array_equal(dm, s.get_datamatrix())}")

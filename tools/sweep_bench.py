@@ -8,10 +8,11 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import carparkingmaps_amd as cpm
 from carparkingmaps_amd import model_selection as ms
-from oracle import oracle as O   # synthetic input generator only
+import _synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=2357)
@@ -21,7 +22,7 @@ args = ap.parse_args()
 Z, T, cpz = args.zones, 24, args.cpz
 C = Z * cpz
 t0 = time.perf_counter()
-dm, dist = O.synth_datamatrix(Z, T, 0x5EED7AB1E)
+dm, dist = _synth.datamatrix(Z, T)
 print(f"synthetic datamatrix {dm.nbytes / 1e9:.2f} GB in {time.perf_counter() - t0:.1f} s", flush=True)
 rng = np.random.default_rng(1)
 with cpm.Sampler(Z, T) as s:

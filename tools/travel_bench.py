@@ -6,13 +6,14 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import carparkingmaps_amd as cpm
-from oracle import oracle as O   # synthetic input generator only
+import _synth
 
 Z, T, cpz = 2357, 24, 1000
 C = Z * cpz
-dm, dist = O.synth_datamatrix(Z, T, 0x5EED7AB1E)
+dm, dist = _synth.datamatrix(Z, T)
 with cpm.Sampler(Z, T) as s:
     s.set_datamatrix(dm, dist)
     s.build_p_drive(0.1, 0.9, 0.5, want=False)
