@@ -223,7 +223,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64",  # the contract's arithmetic (f64 CDF compare, 53-bit draws); the default kernel evaluates it on 32-bit high words
+                             # and 64-bit integers with an exact f64 fallback, bit-identical by construction
             "data": "synthetic" + (" (REHEARSAL: gloo, shared GPU -- not a measurement)" if rehearse else ""),
             "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
