@@ -470,7 +470,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     c->Z = Z;
     c->T = T;
     c->Zp = static_cast<int>((Z + 15) / 16 * 16);
-    c->Zq = static_cast<int>((Z + 31) / 32 * 32);
+    c->Zq = cpm::pack_zq(static_cast<int>(Z));
     c->device = device_id;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->cu_count = p.multiProcessorCount;
@@ -599,6 +599,10 @@ int32_t cpm_sync(cpm_ctx *c)
 int32_t cpm_set_p_drive(cpm_ctx *c, const double *p_drive)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!p_drive) return fail(CPM_ERR_ARG, "null p_drive");
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
@@ -615,6 +619,10 @@ int32_t cpm_set_p_drive(cpm_ctx *c, const double *p_drive)
 int32_t cpm_set_p_dest(cpm_ctx *c, const double *p_dest)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!p_dest) return fail(CPM_ERR_ARG, "null p_dest");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
     double *d_p = nullptr;
@@ -633,6 +641,10 @@ int32_t cpm_set_p_dest(cpm_ctx *c, const double *p_dest)
 int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *dist)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!datamatrix || !dist) return fail(CPM_ERR_ARG, "null datamatrix / dist");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T * 2;
     size_t dbytes = sizeof(double) * c->Z * c->Z;
@@ -719,6 +731,10 @@ int32_t cpm_parse_uber_csv(const char *path_to_csv_data, int64_t *n_rows_out, do
 int32_t cpm_createdatamatrix_rows(cpm_ctx *c, int64_t n_rows, const double *rawdata)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (n_rows < 0 || n_rows >= (int64_t(1) << 32) - 1 || (n_rows > 0 && !rawdata)) return fail(CPM_ERR_ARG, "createdatamatrix: bad row list");
     double *d_raw = nullptr;
     if (n_rows > 0) {
@@ -737,6 +753,10 @@ int32_t cpm_createdatamatrix_rows(cpm_ctx *c, int64_t n_rows, const double *rawd
 int32_t cpm_createdatamatrix_csv(cpm_ctx *c, const char *path_to_csv_data, int64_t *n_rows_out)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!path_to_csv_data) return fail(CPM_ERR_ARG, "createdatamatrix: null path");
     cpm::CsvRows rows;
     std::string err = read_csv_noexcept(path_to_csv_data, rows);
@@ -818,6 +838,10 @@ int32_t cpm_get_distance(cpm_ctx *c, double *dist_out)
 int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive, double *out)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!c->have_dm()) return fail(CPM_ERR_STATE, "build_p_drive: datamatrix and distance matrix first (cpm_set_datamatrix, or cpm_createdatamatrix_* + cpm_set_distance_from_centroids)");
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
@@ -841,6 +865,10 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
 int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double *out)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
     double *d_p = nullptr;
@@ -885,6 +913,10 @@ int32_t cpm_get_cdf_row(cpm_ctx *c, int64_t origin1, int64_t hour1, double *out)
 int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
 {
     CTX_TRY(c);
+    {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     size_t pd_bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, pd_bytes));
     hipLaunchKernelGGL(cpm::k_synth_p_drive, dim3(nblk(c->Z * c->T, 256)), dim3(256), 0, c->stream, c->d_pdrive,
@@ -1020,7 +1052,15 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
     CTX_TRY(c);
     if (!parking || !driving) return fail(CPM_ERR_ARG, "null count outputs");
     bool compat = state_out || trans_out;
-    int saved_kernel = c->kernel;
+    struct KernelGuard {  // the kernel choice is overridden for this call only, whichever way the call ends
+        cpm_ctx *c;
+        int saved;
+        ~KernelGuard() { c->kernel = saved; }
+    } kernel_guard{c, c->kernel};
+    {   // a pending IVP is committed with the caller's kernel choice, not with the override below
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
     if (compat) c->kernel = CPM_KERNEL_CAR;  // the per-hour records of every car are kept by this path
     int32_t rc = resample_enqueue(c, seed, flags, c->d_counts);
     size_t zt = static_cast<size_t>(c->Z * c->T);
@@ -1028,12 +1068,14 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         int64_t status = 0;
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        c->status_pending = false;  // this step's status word is dealt with here: resample_enqueue must not grow the regions for it again
         // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
         while (status != 0 && rc == CPM_OK && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
             rc = resample_enqueue(c, seed, flags, c->d_counts);
             if (rc != CPM_OK) break;
             HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            c->status_pending = false;
         }
         if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout
             if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) c->grouped_overflowed = true;
@@ -1041,7 +1083,6 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
             rc = resample_enqueue(c, seed, flags, c->d_counts);
         }
     }
-    c->kernel = saved_kernel;
     if (rc != CPM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(parking, c->d_counts, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(driving, c->d_counts + zt, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));

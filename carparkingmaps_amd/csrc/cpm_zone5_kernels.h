@@ -501,7 +501,7 @@ int32_t zone5_resample(Zone5Work &w5, hipStream_t stream, const double *d_pdrive
         err = std::string(what) + ": " + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
     };
-    const bool v6 = w5.v6 && d_hi && d_last && zone6_path_fits(Zp, n, Z, w5.base.cap_mult);
+    const bool v6 = w5.v6 && d_hi && d_last && d_thr && zone6_path_fits(Zp, n, Z, w5.base.cap_mult);
     hipError_t e = w5.ensure(n, Z, T, cu_count);
     if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
     Zone3Work &w = w5.base;

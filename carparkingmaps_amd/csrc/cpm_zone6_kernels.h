@@ -64,6 +64,9 @@ __host__ __device__ inline int pack_guide_bits(int Z)
     g = g - CPM_GUIDE_SHIFT < 3 ? 3 : g - CPM_GUIDE_SHIFT;
     return g;
 }
+// high words per row: Z, then at least 31 entries of 0xFFFFFFFF (the unclamped stride walk of pack_search reads up to 30 past
+// its bracket), a whole number of 128-B lines
+__host__ __device__ inline int pack_zq(int Z) { return (Z + 31 + 31) / 32 * 32; }
 __host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4; }  // 2^G + 1 entries used (+7 pad: whole 16-B pieces)
 __host__ __device__ inline int pack_row_words(int Zq, int G)  // at least 1 KiB: one whole LDS-DMA wave-instruction
 {
@@ -199,48 +202,78 @@ __device__ __noinline__ uint32_t search_exact_row(const double *__restrict__ cdf
 
 // CPT draws against the staged pack, in lockstep (CPT independent LDS reads in flight per step):
 // dest[c] = first j with hi[j] >= khi[c], ok[c] = the answer is certain (hi[dest] > khi).  want[c] == false: no search.
-// The guide brackets the answer: j in [guide[m], guide[m+1]], m = khi >> sh (entries are clamped to Z-1 and a draw above
-// the row's last high word never searches, so the bracket is in range); then a branch-free lower bound inside the bracket,
-// O(log bracket) whatever the row looks like (long runs of equal values -- zero-probability zones -- included).
+// The guide brackets the answer: j in [L, L + n], L = guide[m], n = guide[m+1] - L, m = khi >> sh (entries are clamped to Z-1
+// and a draw above the row's last high word never searches, so the bracket is in range).  hi[] is non-decreasing over the WHOLE
+// row and padded with 0xFFFFFFFF for >= 31 entries past Z-1 (Zq), so the lower bound inside the bracket is a descending-stride
+// walk that needs no upper clamp: with 2^K > n,  for s = 2^(K-1) .. 1:  if (hi[L + o + s - 1] < khi) o += s  ends at o = the
+// number of entries from L on that lie below khi = the answer's offset (<= n <= 2^K - 1; the largest index read is L + 2^K - 2).
+// K is wave-uniform (the widest bracket among the wave's draws decides): three to five steps of
+// {LDS read, compare, select, add} on the dense synthetic rows.  Brackets of 32 entries and more (rows with long runs of
+// zero-probability zones) take the same walk from a larger K with the probe index clamped to the row.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+
 template <int CPT>
-__device__ __forceinline__ void pack_search(const uint16_t *guide, const uint32_t *hi, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
-                                            int sh, uint32_t hi_last, uint32_t (&dest)[CPT], bool (&ok)[CPT])
+__device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint32_t *hi_g, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
+                                            int sh, uint32_t hi_last, int Zq, uint32_t (&dest)[CPT], bool (&ok)[CPT])
 {
-    uint32_t lo[CPT], n[CPT], any = 0;
+    lds_cu16 *guide = (lds_cu16 *)guide_g;
+    lds_cu32 *hi = (lds_cu32 *)hi_g;
+    uint32_t kk[CPT], lo[CPT], n[CPT], nor = 0;
     bool in[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        in[c] = want[c] && khi[c] <= hi_last;
-        const uint32_t m = in[c] ? khi[c] >> sh : 0u;
+        in[c] = want[c] & (khi[c] <= hi_last);
+        kk[c] = in[c] ? khi[c] : 0u;  // (a draw that does not search never moves: nothing is below 0)
+        const uint32_t m = kk[c] >> sh;
         lo[c] = guide[m];
         n[c] = guide[m + 1];
     }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         n[c] = in[c] ? n[c] - lo[c] : 0u;
-        any |= n[c];
+        nor |= n[c];
     }
-    while (__any(any != 0)) {  // wave-uniform trips: the longest bracket of the wave
-        uint32_t v[CPT], idx[CPT], half[CPT];
+    if (__builtin_expect(__any(nor >= 32u), 0)) {  // wave-uniform
+        int K = 6;
+        while (__any((nor >> K) != 0u)) ++K;
+        for (uint32_t s = 1u << (K - 1); s != 0u; s >>= 1) {
+            uint32_t v[CPT];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            half[c] = n[c] >> 1;
-            idx[c] = lo[c] + half[c];
-            v[c] = hi[idx[c]];
-        }
-        any = 0;
+            for (int c = 0; c < CPT; ++c) v[c] = hi[min(lo[c] + s - 1u, static_cast<uint32_t>(Zq - 1))];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const bool lt = n[c] != 0 && v[c] < khi[c];
-            lo[c] = lt ? idx[c] + 1 : lo[c];
-            n[c] = lt ? n[c] - half[c] - 1 : half[c];
-            any |= n[c];
+            for (int c = 0; c < CPT; ++c) lo[c] += (v[c] < kk[c]) ? s : 0u;
         }
+    } else {
+        lds_cu32 *p[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) p[c] = hi + lo[c];
+#define CPM_PACK_STEP(S)                                                    \
+    do {                                                                    \
+        uint32_t v_[CPT];                                                   \
+        _Pragma("unroll") for (int c = 0; c < CPT; ++c) v_[c] = p[c][(S) - 1]; \
+        _Pragma("unroll") for (int c = 0; c < CPT; ++c) p[c] += (v_[c] < kk[c]) ? (S) : 0; \
+    } while (0)
+        const bool a16 = __any(nor >= 16u);
+        const bool a8 = a16 || __any(nor >= 8u);
+        if (a16) CPM_PACK_STEP(16);
+        if (a8) CPM_PACK_STEP(8);
+        CPM_PACK_STEP(4);
+        CPM_PACK_STEP(2);
+        CPM_PACK_STEP(1);
+#undef CPM_PACK_STEP
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {  // (LDS addresses are 32 bits wide: a plain pointer difference would be done in 64)
+            const uint32_t fin = p[c][0];
+            dest[c] = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p[c])) - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(hi))) >> 2;
+            ok[c] = in[c] & (fin > kk[c]);
+        }
+        return;
     }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         dest[c] = lo[c];
-        ok[c] = in[c] && hi[lo[c]] > khi[c];
+        ok[c] = in[c] & (hi[lo[c]] > kk[c]);
     }
 }
 
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
     // ids are in their registers.  (The waitcnt statement names the ids as in/out operands: no use can move above it.)
     const uint32_t n_raw = a.cnt[z];  // (scalar loads: requested before the statements below fence memory operations)
     const double last = a.last_t[z];
-    const double pd = a.pdrive_t[z];
+    const long long thr = a.thr_t[z];  // scalar too: a vector load here would be waited for with vmcnt(0), i.e. behind the whole pack
     uint32_t id[CPT + 1];
 #pragma unroll
     for (int c = 0; c <= CPT; ++c) {
@@ -307,7 +340,6 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
     const uint32_t n = min(n_raw, cap);
-    const long long thr = a.thr_t ? a.thr_t[z] : bernoulli_threshold(pd);
     if (tid == 0) {
         a.parking_t[z] = n;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         s_ndrive = 0;
@@ -336,10 +368,13 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         } else {
             car_draw_words(a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step, kb, clo[c], khi[c]);
         }
-        drive[c] = valid[c] && (kb <= thr);
-        want[c] = drive[c] && last != 0.0;  // stays, or zero row: destination = origin (:35-36)
+        drive[c] = valid[c] & (kb <= thr);
+        want[c] = drive[c] & (last != 0.0);  // stays, or zero row: destination = origin (:35-36)
     }
     CPM_STAMP(a, z, 1);
+    // This wave's pieces of the pack have landed (LDS-DMA counts in vmcnt; s_barrier itself waits for no counter), then the
+    // barrier makes every wave's pieces visible to every wave.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CPM_STAMP(a, z, 2);
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
@@ -360,12 +395,21 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
                 ok[c] = true;
             }
         } else {
-            pack_search<CPT>(guide, hi, khi, want, sh, hi_last, dest, ok);
+            pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+        }
+        bool anyx = false;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
+            anyx |= want[c] & !ok[c];
+        }
+        if (__builtin_expect(__any(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
         }
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            if (!want[c]) dest[c] = z;
-            else if (!ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
             if (drive[c]) {
                 if (!GROUPED) ++nd;  // (grouped: drivers = bucket size - stayers)
                 if (TRAVEL) tt += travel_time_q16(a.dm, Z, a.T, a.t, z, dest[c], a.seed, static_cast<uint64_t>(a.car_begin) + id[c], a.step);
@@ -411,6 +455,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         s_nstay = n;
     }
     for (uint32_t q0 = CPT * BLOCK; q0 < n && !CPM_ABL(a, 32); q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
+        if (q0 + static_cast<uint32_t>(tid & ~63) >= n) continue;  // none of this wave's 64 slots holds a car (no barrier inside the loop)
         const uint32_t q = q0 + tid;
         const bool valid1 = q < n;
         const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q] : 0u);
@@ -421,7 +466,7 @@ __global__ __launch_bounds__(BLOCK, TRAVEL ? 2 : CPM_WPS) void k_zone6_sample(Zo
         car_draw_words(a.seed, car, a.step, kb, clo1[0], khi1[0]);
         const bool drive1 = valid1 && (kb <= thr);
         want1[0] = drive1 && last != 0.0;
-        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, dest1, ok1);
+        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
         if (!want1[0]) dest1[0] = z;
         else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
         if (drive1) {
@@ -734,8 +779,7 @@ inline void zone6_launch(const Zone6Args &a, bool travel, int64_t mean, hipStrea
 inline bool zone6_row_fits(int Z)
 {
     if (Z < 2 || Z > 32768) return false;
-    const int Zq = (Z + 31) / 32 * 32;
-    return sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, pack_guide_bits(Z))) <= 150 * 1024;
+    return sizeof(uint32_t) * static_cast<size_t>(pack_row_words(pack_zq(Z), pack_guide_bits(Z))) <= 150 * 1024;
 }
 
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
@@ -757,6 +801,7 @@ __global__ __launch_bounds__(512) void k_zone6_search_debug(const uint32_t *__re
                                                  (__attribute__((address_space(3))) void *)(pack + 4 * p0), 16, 0, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
@@ -772,7 +817,7 @@ __global__ __launch_bounds__(512) void k_zone6_search_debug(const uint32_t *__re
         bool ok[1];
         const uint32_t khi[1] = {static_cast<uint32_t>(k >> 21)};
         const bool want[1] = {true};
-        pack_search<1>(guide, hi, khi, want, sh, hi_last, dest, ok);
+        pack_search<1>(guide, hi, khi, want, sh, hi_last, Zq, dest, ok);
         if (!ok[0]) {
             dest[0] = search_exact_row(cdf_row, Z, static_cast<double>(k) * 0x1.0p-53, last);
             atomicAdd(n_exact, 1);

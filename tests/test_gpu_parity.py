@@ -731,6 +731,36 @@ def test_overflow_is_absorbed_by_growing_the_bucket_regions(cpm, O):
         assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
 
 
+def test_async_ivp_is_committed_on_the_tables_it_was_enqueued_with(cpm, O):
+    """solve_ivp_async, then new tables, then a read of the state: the IVP must have run on the OLD tables whether or not its first
+    attempt overflowed the bucket regions (an overflowed attempt is repeated by the library when the state is next needed -- every
+    entry that replaces a table commits the pending IVP first)."""
+    Z, T, cpz = 64, 24, 800
+    C = Z * cpz
+    p_drive = np.full((Z, T), 0.5, order="F")
+    w = np.ones(Z)
+    w[7] = 7.0                       # zone 8 holds ~6.4x the mean: overflows the default regions (4x) during the IVP
+    p_dest = np.zeros((Z, Z, T), order="F")
+    p_dest[:, :, :] = (w / w.sum())[None, :, None]
+    flat_drive, flat_dest = _tables(O, Z, T)     # the tables installed afterwards: no overflow, different results
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz))
+    other = O.fast_run(flat_drive, O.build_cdf(flat_dest), C, SIM_SEED, _zone0(C, cpz))
+    assert not np.array_equal(ref["zone0"], other["zone0"])
+    for swap in ("p_dest", "p_drive", "both"):
+        with cpm.Sampler(Z, T) as s:
+            s.set_p_drive(p_drive)
+            s.set_p_dest(p_dest)
+            s.init_states(C, cpz)
+            assert s.get_info(2) == 4
+            s.solve_ivp_async(SIM_SEED)
+            if swap in ("p_dest", "both"):
+                s.set_p_dest(flat_dest)
+            if swap in ("p_drive", "both"):
+                s.set_p_drive(flat_drive)
+            assert np.array_equal(s.get_state(), ref["zone0"]), swap
+            assert s.get_info(2) == 8            # the first attempt did overflow and was repeated with grown regions
+
+
 def test_examples_main_py_on_a_city_directory(cpm, O, tmp_path):
     """examples/main.py (main.jl line for line) in both modes on a small synthetic city: same result files."""
     import json
