@@ -79,13 +79,13 @@ def pmc_traffic(kernel, Z, cars_per_gpu):
     MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  None when no run matches."""
     if Z != 4096 or cars_per_gpu != 4096000:
         return None, None
-    name = {0: "k_zone6_sample", 5: "k_zone6_sample", 2: "k_zone_sample", 4: "k_zone_sample", 1: "k_step_car"}[kernel]
+    name = {0: "k_grouped_sample", 5: "k_grouped_sample", 2: "k_exact_sample", 1: "k_step_car"}[kernel]
     for f in ("round1_gen6_traffic.json", "round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             for k, v in json.load(open(path)).items():
-                # (the grouped form of k_zone6_sample: last template argument true; the plain form only runs the last hour)
-                if name in k and v.get("launches", 0) > 0 and (name != "k_zone6_sample" or ", true>(" in k):
+                # (the grouped form of k_grouped_sample: last template argument true; the plain form only runs the last hour)
+                if name in k and v.get("launches", 0) > 0 and (name != "k_grouped_sample" or ", true>(" in k):
                     return v["hbm_bytes_per_launch"], "profiles/" + f
     return None, None
 
@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--zones", type=int, default=4096)
     ap.add_argument("--cars-per-zone", type=int, default=1000, help="per GPU (weak scaling)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 4 zone_strided, 5 zone_grouped")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 5 zone_grouped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -229,8 +229,7 @@ def main():
             "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
                                    f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
-                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 4: "zone_strided",
-                                  5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " (not the requested one: AUTO's choice or overflow fallback)"),
+                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " (not the requested one: AUTO's choice or overflow fallback)"),
                        "bucket_region_x_mean": s.get_info(2),
                        "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),

@@ -6,7 +6,7 @@ The compute lives in csrc/libcpm_hip.so (hand-written HIP, C ABI in include/cpm.
 no CPU fallback; importing the package works without a GPU, computing does not.
 """
 from . import _lib
-from ._lib import (CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_GROUPED, CPM_KERNEL_ZONE_LDS, CPM_KERNEL_ZONE_STRIDED,
+from ._lib import (CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_GROUPED, CPM_KERNEL_ZONE_LDS,
                    CpmError)
 from .sampler import Sampler, device_count, device_info
 from .reference_api import (DeviceArray, Params, averagedrivingtime, correctparameters, createdatamatrix, createpdestin,
@@ -16,7 +16,7 @@ from .reference_api import (DeviceArray, Params, averagedrivingtime, correctpara
 
 __all__ = [
     "Sampler", "device_count", "device_info", "CpmError", "CPM_KERNEL_AUTO", "CPM_KERNEL_CAR",
-    "CPM_KERNEL_ZONE_LDS", "CPM_KERNEL_ZONE_STRIDED", "CPM_KERNEL_ZONE_GROUPED", "Params", "params", "createpdrive", "createpdestin", "initializestates",
+    "CPM_KERNEL_ZONE_LDS", "CPM_KERNEL_ZONE_GROUPED", "Params", "params", "createpdrive", "createpdestin", "initializestates",
     "solveinitialvalueproblem", "resampling", "averagedrivingtime", "correctparameters", "saveresults",
     "zone_hour_counts", "run_dataset", "release", "createdatamatrix", "processgeodata", "createresultsdirectory",
     "saveparameters", "DeviceArray",

@@ -20,13 +20,13 @@ SYMBOLS = [
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
     "cpm_debug_categorical", "cpm_createdatamatrix_rows", "cpm_createdatamatrix_csv", "cpm_get_datamatrix",
     "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv", "cpm_set_distance", "cpm_get_info",
+    "cpm_init_states_strided",
 ]
 
 CPM_FLAG_TRAVEL = 1
 CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
-CPM_KERNEL_ZONE_STRIDED, CPM_KERNEL_ZONE_GROUPED = 4, 5
+CPM_KERNEL_ZONE_GROUPED = 5
 CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
-CPM_OPT_PLACE_SHAPE, CPM_OPT_GROUPED_GEN = 4, 5
 
 _lib = None
 
@@ -85,6 +85,7 @@ def load():
     L.cpm_get_p_drive.argtypes = [vp, vp]
     L.cpm_get_cdf_row.argtypes = [vp, i64, i64, vp]
     L.cpm_init_states.argtypes = [vp, i64, i64, i64, i64]
+    L.cpm_init_states_strided.argtypes = [vp, i64, i64, i64, i64, i64]
     L.cpm_set_state.argtypes = [vp, vp]
     L.cpm_get_state.argtypes = [vp, vp]
     L.cpm_solve_ivp.argtypes = [vp, u64, vp]

@@ -13,9 +13,8 @@
 #include "../../include/cpm.h"
 #include "cpm_kernels.h"
 #include "cpm_tables.h"
-#include "cpm_zone_kernels.h"
-#include "cpm_zone3_kernels.h"
-#include "cpm_zone5_kernels.h"
+#include "cpm_exact.h"
+#include "cpm_grouped.h"
 #include "cpm_ingest.h"
 
 namespace {
@@ -66,7 +65,7 @@ struct cpm_ctx {
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
     double *d_cdf = nullptr;     // [T][Z][Zp]
-    uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_zone6_kernels.h)
+    uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_grouped.h)
     double *d_last = nullptr;    // [T][Z] row totals
     long long *d_thr = nullptr;  // [T][Z] Bernoulli thresholds of p_drive (k_build_thr), rebuilt whenever p_drive changes
     int Zq = 0;
@@ -75,7 +74,8 @@ struct cpm_ctx {
     bool have_pdrive = false, have_cdf = false, have_dmat = false, have_dist = false;
     bool have_dm() const { return have_dmat && have_dist; }
     // cars
-    int64_t C_total = 0, cpz = 0, car_begin = 0, n = 0;
+    int64_t C_total = 0, cpz = 0, n = 0;
+    cpm::CarIndex cars{0, 1};     // local car i = global car cars.begin + i * cars.stride
     uint32_t *d_zone0 = nullptr;  // [n] current zones
     uint32_t *d_ztmp = nullptr;   // [n] ping-pong for the IVP
     uint32_t *d_rec = nullptr;    // [T][n]
@@ -84,19 +84,18 @@ struct cpm_ctx {
     // results
     int64_t *d_counts = nullptr;  // [2*T*Z + 2]
     int *d_err = nullptr;
-    // zone-bucket path
-    cpm::ZoneWork zw;
-    cpm::Zone3Work zw3;
-    cpm::Zone5Work zw5;
-    // AUTO demotes itself from the fixed-stride layouts to the exact one after the first overflow: the status
-    // word of every fixed-stride step is copied to pinned host memory behind the step and looked at, without
+    // zone-bucket paths
+    cpm::ExactWork zx;
+    cpm::GroupedWork zg;
+    // AUTO moves from the grouped (fixed-stride) layout to the exact one after an overflow that growing the regions could not
+    // absorb: the status word of every grouped step is copied to pinned host memory behind the step and looked at, without
     // waiting, when the next step is enqueued (the overflowed step itself is flagged in its own status word).
     bool grouped_overflowed = false;
     long long *h_status = nullptr;      // pinned
     hipEvent_t status_ev = nullptr;
     bool status_pending = false;
-    // An IVP enqueued on the fixed-stride layout writes the new state beside the old one; it is committed (or
-    // repeated on the exact layout) by finish_ivp() before anything reads or replaces the state.
+    // An IVP enqueued on the grouped layout writes the new state beside the old one; it is committed (or repeated) by
+    // finish_ivp() before anything reads or replaces the state or the tables.
     bool ivp_pending = false;
     uint64_t ivp_seed = 0;
     long long *h_ivp_status = nullptr;  // pinned
@@ -172,7 +171,7 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
     int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)",
                                 CPM_ERR_TABLE);
     if (rc != CPM_OK) return rc;
-    if (cpm::zone6_row_fits(static_cast<int>(c->Z))) {  // the row packs (guide + high words) of the grouped zone path
+    if (cpm::pack_row_fits(static_cast<int>(c->Z))) {  // the row packs (guide + high words) of the grouped zone path
         const int64_t rows = c->T * c->Z;
         const int G = cpm::pack_guide_bits(static_cast<int>(c->Z));
         const size_t words = static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, G);
@@ -186,19 +185,24 @@ int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
         HIP_TRY(hipGetLastError());
     }
     c->have_cdf = true;
-    c->zw.tables_dirty = true;
+    c->zx.tables_dirty = true;
     return CPM_OK;
 }
 
-// AUTO: a zone-bucketed LDS path when a CDF row fits in LDS and there are enough cars per zone to
-// amortise streaming every row once per hour (the grouped fixed-stride form while no bucket has ever
-// outgrown its region in this context, else the exact layout); otherwise one thread per car.
+bool grouped_fits(const cpm_ctx *c, int cap_mult)
+{
+    return c->d_hi && c->d_last && c->d_thr && cpm::grouped_path_fits(c->n, static_cast<int>(c->Z), cap_mult);
+}
+
+// AUTO: a zone-bucketed LDS path when a row fits in LDS and there are enough cars per zone to amortise streaming every row once
+// per hour (the grouped fixed-stride form while no overflow went unabsorbed in this context, else the exact layout); otherwise
+// one thread per car.
 int pick_kernel(const cpm_ctx *c)
 {
     if (c->kernel != CPM_KERNEL_AUTO) return c->kernel;
-    if (cpm::zone_path_fits(c->Zp) && c->n >= 32 * c->Z && c->n < (int64_t(1) << 32)) {
-        if (!c->grouped_overflowed && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult)) return CPM_KERNEL_ZONE_GROUPED;
-        return CPM_KERNEL_ZONE_LDS;
+    if (c->n >= 32 * c->Z && c->n < (int64_t(1) << 30)) {
+        if (!c->grouped_overflowed && grouped_fits(c, c->zg.cap_mult)) return CPM_KERNEL_ZONE_GROUPED;
+        if (cpm::exact_path_fits(static_cast<int>(c->Z))) return CPM_KERNEL_ZONE_LDS;
     }
     return CPM_KERNEL_CAR;
 }
@@ -207,11 +211,26 @@ int pick_kernel(const cpm_ctx *c)
 // enqueue re-allocates the workspace.  false: no room to grow -- the caller falls back to the exact layout for good.
 bool grow_grouped(cpm_ctx *c)
 {
-    const int next = c->zw5.base.cap_mult * 2;
-    if (next > cpm::kMaxCapMult || !cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), next)) return false;
-    c->zw5.base.cap_mult = next;
-    c->zw5.base.buckets0_valid = false;
+    const int next = c->zg.cap_mult * 2;
+    if (next > cpm::kMaxCapMult || !grouped_fits(c, next)) return false;
+    c->zg.cap_mult = next;
+    c->zg.buckets0_valid = false;
     return true;
+}
+
+cpm::GroupedTables grouped_tables(const cpm_ctx *c)
+{
+    cpm::GroupedTables tb;
+    tb.rp = c->d_hi;
+    tb.last = c->d_last;
+    tb.thr = c->d_thr;
+    tb.cdf = c->d_cdf;
+    tb.dm = c->d_dm;
+    tb.Z = static_cast<int>(c->Z);
+    tb.Zp = c->Zp;
+    tb.Zq = c->Zq;
+    tb.T = static_cast<int>(c->T);
+    return tb;
 }
 
 constexpr int kMaxProf = 8192;
@@ -250,10 +269,10 @@ int32_t launch_step_car(cpm_ctx *c, const uint32_t *zin, uint32_t *out, int t, u
     dim3 grid(nblk(c->n, 256)), block(256);
     if (travel)
         hipLaunchKernelGGL(cpm::k_step_car<true>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
-                           c->Zp, c->n, c->car_begin, step, seed, c->d_dm, static_cast<int>(c->T), t, tt_sum);
+                           c->Zp, c->n, c->cars, step, seed, c->d_dm, static_cast<int>(c->T), t, tt_sum);
     else
         hipLaunchKernelGGL(cpm::k_step_car<false>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
-                           c->Zp, c->n, c->car_begin, step, seed, nullptr, static_cast<int>(c->T), t, nullptr);
+                           c->Zp, c->n, c->cars, step, seed, nullptr, static_cast<int>(c->T), t, nullptr);
     HIP_TRY(hipGetLastError());
     return CPM_OK;
 }
@@ -264,7 +283,7 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
     unsigned long long *driving = parking + c->T * c->Z;
     size_t lds = sizeof(uint32_t) * 2 * c->Z;
     if (lds <= 160 * 1024) {
-        if (lds > 64 * 1024)
+        if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_histogram),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         // enough chunks to fill the chip, few enough that the flush (2*Z atomics per block) stays small
@@ -302,13 +321,12 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) {
-        if (!cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult))
-            return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
-        int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                         static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
-                                         d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                         g_last_error, false, nullptr, c->d_hi, c->d_last, c->Zq, c->d_thr);
+    const int kernel = pick_kernel(c);
+    if (kernel == CPM_KERNEL_ZONE_GROUPED) {
+        if (!grouped_fits(c, c->zg.cap_mult))
+            return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR)");
+        int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, travel, d_counts, c->cu_count,
+                                      [&](int) { prof_begin(c); }, [&](int) { prof_end(c); }, g_last_error);
         if (rc == CPM_OK && c->h_status && !c->status_pending) {
             if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                 hipEventRecord(c->status_ev, c->stream) == hipSuccess)
@@ -316,19 +334,10 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         }
         return rc;
     }
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_STRIDED) {
-        if (!cpm::zone3_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw3.cap_mult))
-            return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_STRIDED does not fit this problem (use CPM_KERNEL_ZONE_LDS)");
-        return cpm::zone3_resample(c->zw3, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                   static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
-                                   d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                   g_last_error);
-    }
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_LDS) {
-        return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, travel, c->d_dm,
-                                  d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
-                                  g_last_error);
+    if (kernel == CPM_KERNEL_ZONE_LDS) {
+        return cpm::exact_run(c->zx, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp, static_cast<int>(c->T), c->n, c->cars,
+                              c->d_zone0, seed, travel, c->d_dm, d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                              g_last_error);
     }
     int32_t rc = ensure_rec(c);
     if (rc != CPM_OK) return rc;
@@ -343,12 +352,12 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     return launch_histogram(c, d_counts);
 }
 
+// the IVP on a layout that cannot overflow: exact buckets when the row fits LDS, one thread per car otherwise
 int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
 {
-    if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::zone_path_fits(c->Zp)) {
-        return cpm::zone_resample(c->zw, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                  static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr,
-                                  c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
+    if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::exact_path_fits(static_cast<int>(c->Z))) {
+        return cpm::exact_run(c->zx, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp, static_cast<int>(c->T), c->n, c->cars,
+                              c->d_zone0, seed, false, nullptr, c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
     }
     // src/solveinitialvalueproblem.jl:8 : t = 1:(T-1), state update unconditional (:53)
     for (int t = 0; t < c->T - 1; ++t) {
@@ -362,20 +371,17 @@ int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
 // The IVP on the grouped layout: new state beside the old one (d_ztmp), status word copied to pinned memory behind it.
 int32_t ivp_grouped(cpm_ctx *c, uint64_t seed)
 {
-    // the current state's buckets may be cached (zw5); everything else is stale once the IVP is committed
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
+    c->zx.buckets0_valid = false;  // the current state's grouped buckets may be cached (zg); everything else is stale once the IVP is committed
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
-    int32_t rc = cpm::zone5_resample(c->zw5, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp,
-                                     static_cast<int>(c->T), c->n, c->car_begin, c->d_zone0, seed, false, nullptr, c->d_counts,
-                                     c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp, c->d_hi, c->d_last, c->Zq, c->d_thr);
+    int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, false, c->d_counts, c->cu_count,
+                                  [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp);
     if (rc != CPM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     return CPM_OK;
 }
 
-// Commit (or repeat on the exact layout) an IVP that was enqueued on the fixed-stride layout.  Called before
-// anything reads or replaces the car state.  Blocks until the IVP has drained.
+// Commit (or repeat) an IVP that was enqueued on the grouped layout.  Called before anything reads or replaces the car
+// state or the tables.  Blocks until the IVP has drained.
 int32_t finish_ivp(cpm_ctx *c)
 {
     if (!c->ivp_pending) return CPM_OK;
@@ -383,7 +389,7 @@ int32_t finish_ivp(cpm_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (*c->h_ivp_status == 0) {
         std::swap(c->d_zone0, c->d_ztmp);
-        HIP_TRY(cpm::zone5_commit_ivp(c->zw5, c->stream));
+        HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
         return CPM_OK;
     }
     // A bucket or a run outgrew its region: d_zone0 is untouched.  Run the IVP again with twice the regions while the problem
@@ -394,14 +400,13 @@ int32_t finish_ivp(cpm_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (*c->h_ivp_status == 0) {
             std::swap(c->d_zone0, c->d_ztmp);
-            HIP_TRY(cpm::zone5_commit_ivp(c->zw5, c->stream));
+            HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
             return CPM_OK;
         }
     }
-    c->grouped_overflowed = true;
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
-    c->zw5.base.buckets0_valid = false;
+    if (c->kernel == CPM_KERNEL_AUTO) c->grouped_overflowed = true;
+    c->zx.buckets0_valid = false;
+    c->zg.buckets0_valid = false;
     return ivp_exact(c, c->ivp_seed);
 }
 
@@ -412,16 +417,15 @@ int32_t ivp_enqueue(cpm_ctx *c, uint64_t seed)
     int32_t rc = finish_ivp(c);
     if (rc != CPM_OK) return rc;
     if (c->n == 0) return CPM_OK;
-    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && cpm::zone5_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult)) {
+    if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grouped_fits(c, c->zg.cap_mult)) {
         rc = ivp_grouped(c, seed);
         if (rc != CPM_OK) return rc;
         c->ivp_pending = true;
         c->ivp_seed = seed;
         return CPM_OK;
     }
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
-    c->zw5.base.buckets0_valid = false;
+    c->zx.buckets0_valid = false;
+    c->zg.buckets0_valid = false;
     return ivp_exact(c, seed);
 }
 
@@ -509,9 +513,8 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_rec);
     dfree(c->d_counts);
     dfree(c->d_err);
-    c->zw.release();
-    c->zw3.release();
-    c->zw5.release();
+    c->zx.release();
+    c->zg.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_ivp_status) (void)hipHostFree(c->h_ivp_status);
     if (c->status_ev) (void)hipEventDestroy(c->status_ev);
@@ -526,7 +529,7 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
     CTX_TRY(c);
     switch (option) {
     case CPM_OPT_KERNEL:
-        if (value < CPM_KERNEL_AUTO || value > CPM_KERNEL_ZONE_GROUPED || value == 3) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value != CPM_KERNEL_AUTO && value != CPM_KERNEL_CAR && value != CPM_KERNEL_ZONE_LDS && value != CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE:
@@ -534,26 +537,6 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->prof_stride = value > 1 ? static_cast<int>(value) : 1;
         c->prof_seen = 0;
         c->n_prof = 0;  // (re)start the record; hourly launches append until read or reset
-        return CPM_OK;
-    case CPM_OPT_ZONE_BLOCK:
-        // 0: the default tree-layout sampler; 256 / 512: the first-generation sorted-row sampler of that size
-        if (value != 0 && value != 256 && value != 512) return fail(CPM_ERR_ARG, "zone block %lld", (long long)value);
-        c->zw.tree = (value == 0);
-        if (value) c->zw.block = static_cast<int>(value);
-        return CPM_OK;
-    case CPM_OPT_PLACE_SHAPE:
-        if (value != 0 && value != 81 && value != 82 && value != 161 && value != 162) return fail(CPM_ERR_ARG, "place shape %lld", (long long)value);
-        if (value && (c->Z + value / 10 - 1) / (value / 10) > 512) return fail(CPM_ERR_ARG, "place shape %lld: too few blocks for %lld zones", (long long)value, (long long)c->Z);
-        c->zw5.bpg = static_cast<int>(value / 10);
-        c->zw5.deep = static_cast<int>(value % 10);
-        return CPM_OK;
-    case CPM_OPT_GROUPED_GEN:
-        if (value != 5 && value != 6) return fail(CPM_ERR_ARG, "grouped generation %lld", (long long)value);
-        c->zw5.v6 = (value == 6);
-        return CPM_OK;
-    case CPM_OPT_ABLATE:
-        c->zw.ablate = static_cast<int>(value);
-        c->zw5.base.sampler.ablate = static_cast<int>(value);
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown option %d", option);
@@ -568,7 +551,7 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         *value_out = pick_kernel(c);
         return CPM_OK;
     case CPM_INFO_CAP_MULT:
-        *value_out = c->zw5.base.cap_mult;
+        *value_out = c->zg.cap_mult;
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown info %d", what);
@@ -942,34 +925,39 @@ int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
 
 // ------------------------------------------------------------------ cars
 
-int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int64_t car_begin, int64_t car_count)
+int32_t cpm_init_states_strided(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int64_t car_first, int64_t car_stride, int64_t car_count)
 {
     CTX_TRY(c);
     if (c->ivp_pending) {  // the state is being replaced: the pending IVP's result is moot
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->ivp_pending = false;
     }
-    if (C_total < 0 || cars_per_zone < 1 || car_begin < 0 || car_count < 0 || car_begin + car_count > C_total)
-        return fail(CPM_ERR_ARG, "init_states: bad car range [%lld, +%lld) of %lld", (long long)car_begin,
+    if (C_total < 0 || cars_per_zone < 1 || car_first < 0 || car_count < 0 || car_stride < 1 || car_stride > 0x7fffffffLL ||
+        (car_count > 0 && car_first + (car_count - 1) * car_stride >= C_total))
+        return fail(CPM_ERR_ARG, "init_states: bad car set {%lld + k * %lld, k < %lld} of %lld", (long long)car_first, (long long)car_stride,
                     (long long)car_count, (long long)C_total);
     if (C_total > 0 && (C_total - 1) / cars_per_zone >= c->Z)
         return fail(CPM_ERR_ARG, "init_states: C = %lld cars at %lld per zone exceed %lld zones", (long long)C_total,
                     (long long)cars_per_zone, (long long)c->Z);
+    if (car_count >= (int64_t(1) << 32)) return fail(CPM_ERR_ARG, "init_states: more than 2^32 cars in one context");
     int32_t rc = ensure_cars(c, car_count);
     if (rc != CPM_OK) return rc;
     c->C_total = C_total;
     c->cpz = cars_per_zone;
-    c->car_begin = car_begin;
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
-    c->zw5.base.buckets0_valid = false;
+    c->cars = cpm::CarIndex{car_first, static_cast<uint32_t>(car_stride)};
+    c->zx.buckets0_valid = false;
+    c->zg.buckets0_valid = false;
     if (car_count > 0) {
-        hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, car_begin,
-                           car_count, cars_per_zone);
+        hipLaunchKernelGGL(cpm::k_init_states, dim3(nblk(car_count, 256)), dim3(256), 0, c->stream, c->d_zone0, c->cars, car_count, cars_per_zone);
         HIP_TRY(hipGetLastError());
     }
     c->have_state = true;
     return CPM_OK;
+}
+
+int32_t cpm_init_states(cpm_ctx *c, int64_t C_total, int64_t cars_per_zone, int64_t car_begin, int64_t car_count)
+{
+    return cpm_init_states_strided(c, C_total, cars_per_zone, car_begin, 1, car_count);
 }
 
 int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
@@ -980,9 +968,8 @@ int32_t cpm_set_state(cpm_ctx *c, const int64_t *zones)
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->ivp_pending = false;
     }
-    c->zw.buckets0_valid = false;
-    c->zw3.buckets0_valid = false;
-    c->zw5.base.buckets0_valid = false;
+    c->zx.buckets0_valid = false;
+    c->zg.buckets0_valid = false;
     if (c->n == 0) return CPM_OK;
     if (!zones) return fail(CPM_ERR_ARG, "null zones");
     int64_t *d_z = nullptr;
@@ -1079,7 +1066,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         }
         if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout
             if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) c->grouped_overflowed = true;
-            c->kernel = CPM_KERNEL_ZONE_LDS;
+            c->kernel = cpm::exact_path_fits(static_cast<int>(c->Z)) ? CPM_KERNEL_ZONE_LDS : CPM_KERNEL_CAR;
             rc = resample_enqueue(c, seed, flags, c->d_counts);
         }
     }
@@ -1102,7 +1089,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         for (int t = 0; t < c->T && e == hipSuccess; ++t) {
             const uint32_t *zsrc = (t == 0) ? c->d_zone0 : c->d_rec + static_cast<size_t>(t - 1) * n;
             hipLaunchKernelGGL(cpm::k_export_hour, dim3(nblk(n, 256)), dim3(256), 0, c->stream, zsrc,
-                               c->d_rec + static_cast<size_t>(t) * n, n, c->car_begin, d_state, d_f, d_f + n, d_f + 2 * n,
+                               c->d_rec + static_cast<size_t>(t) * n, n, c->cars, d_state, d_f, d_f + n, d_f + 2 * n,
                                d_f + 3 * n, travel ? c->d_dm : nullptr, c->d_dist, static_cast<int>(c->Z),
                                static_cast<int>(c->T), t, static_cast<uint32_t>(c->T - 1 + t), seed);
             e = hipGetLastError();
@@ -1136,8 +1123,7 @@ int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
     // B/T = Z*Z*8 (CDF slab) + Z*8 (p_drive) + C_g*8 (4 B zone in + 4 B out) + 2*Z*8 (counts)
     // The second-generation grouped path streams the 4-byte high-word rows (Zq per row) instead of the f64 rows:
     // its true element size is substituted, as 8(d) prescribes for a variant with a different element size.
-    const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zw5.v6 && c->d_hi &&
-                         cpm::zone6_path_fits(c->Zp, c->n, static_cast<int>(c->Z), c->zw5.base.cap_mult);
+    const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grouped_fits(c, c->zg.cap_mult);
     const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))) * 4 + c->Z * 8
                                  : c->Z * c->Z * 8;
     *bytes_out = rows + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
@@ -1167,8 +1153,8 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
         const size_t words = static_cast<size_t>(cpm::pack_row_words(c->Zq, G));
         const size_t lds = sizeof(uint32_t) * words;
         if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_zone6_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(cpm::k_zone6_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_pack_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(cpm::k_pack_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
                            c->d_cdf + row * c->Zp, static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
         e = hipGetLastError();
     }

@@ -1,24 +1,23 @@
-// cpm_zone_kernels.h -- the zone sampler, and CPM_KERNEL_ZONE_LDS: the zone path on the exact
-// (packed) bucket layout.  cpm_zone3_kernels.h / cpm_zone5_kernels.h reuse the sampler on
-// fixed-stride buckets.
+// cpm_exact.h -- CPM_KERNEL_ZONE_LDS: the zone path on the exact (packed) bucket layout.  The fallback of the grouped path
+// (cpm_grouped.h) when a bucket or run outgrows its fixed region and the regions cannot grow any further, and an A/B reference.
 //
 // The reference walks p_dest[origin,:,t] once per driving car (src/resampling.jl:34-45).  Here
 // the cars of one origin zone sit together, so the row is streamed from HBM exactly once per
 // hour (coalesced, 16 B per lane), kept in LDS, and every car of the zone searches it there.
 // Per hour t:
-//   k_zone_sample2  one workgroup per origin zone: stage cdf[t][zone][:] in LDS (as a breadth-first
+//   k_exact_sample  one workgroup per origin zone: stage cdf[t][zone][:] in LDS (as a breadth-first
 //                   search tree); for each car of the bucket: Philox -> Bernoulli (:11-22) -> categorical
 //                   by tree walk in LDS (:26-49); writes dest|drive per slot, parking[t][zone] = bucket
 //                   size, driving[t][zone] = drivers (src/saveresults.jl:10-15) -- no histogram atomics.
-//                   (k_zone_sample: the first-generation form, sorted row + binary search, kept for A/B.)
 //   k_zone_hist     counting sort, pass 1: LDS-privatised histogram of the destinations of a
 //                   contiguous chunk of slots; one contiguous global atomic per (block, zone)
 //                   reserves the block's range in the zone's next bucket (ticket).
 //   k_zone_scatter  counting sort, pass 2: every block scans the Z bucket sizes itself (16 KB,
 //                   L2-resident), then moves its car ids to their next-hour buckets.
-// The bucket sizes ARE the parking histogram of the next hour.  The order of ids inside a
-// bucket is arbitrary (it depends on atomic arrival order) and does not matter: a car's draw
-// depends only on (seed, global car id, step) and integer counts are order-free.
+// Buckets are packed (exclusive scan of their sizes), so nothing can overflow.  The bucket sizes ARE the
+// parking histogram of the next hour.  The order of ids inside a bucket is arbitrary (it depends on atomic
+// arrival order) and does not matter: a car's draw depends only on (seed, global car id, step) and integer
+// counts are order-free.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,71 +33,7 @@ namespace cpm {
 constexpr int kZoneBlock = 256;
 constexpr int kSortBlock = 1024;
 
-// ABL (diagnostic builds only, results wrong): 1 = no search, 2 = no Philox, 4 = no row staging
-template <bool TRAVEL, int BLOCK, int ABL>
-__global__ __launch_bounds__(BLOCK) void k_zone_sample(
-    const uint32_t *__restrict__ ids, const uint32_t *__restrict__ off, uint32_t *__restrict__ dest_out,
-    const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int64_t car_begin,
-    uint32_t step, uint64_t seed, unsigned long long *__restrict__ parking_t,
-    unsigned long long *__restrict__ driving_t, const double *__restrict__ dm, int T, int t,
-    unsigned long long *tt_sum)
-{
-    extern __shared__ double row[];  // Zp doubles: the CDF row of this origin zone
-    __shared__ uint32_t s_ndrive;
-    __shared__ unsigned long long s_tt;
-    const int z = blockIdx.x;
-    const int tid = threadIdx.x;
-    const uint32_t b = off[z], e = off[z + 1];
-    if (tid == 0) {
-        parking_t[z] = e - b;  // every car present at hour t, drivers included (Appendix A-14)
-        s_ndrive = 0;
-        s_tt = 0;
-    }
-    if (e == b) return;  // driving_t[z] stays 0 (zeroed by the caller)
-    // stage the row: 16 B per lane, whole 128-B lines
-    const double2 *src = reinterpret_cast<const double2 *>(cdf_t + static_cast<size_t>(z) * Zp);
-    double2 *dst = reinterpret_cast<double2 *>(row);
-    if (!(ABL & 4))
-        for (int i = tid; i < Zp / 2; i += BLOCK) dst[i] = src[i];
-    const double pd = pdrive_t[z];
-    __syncthreads();
-    const double last = row[Z - 1];
-    uint32_t nd = 0;
-    long long tt = 0;
-    for (uint32_t s = b + tid; s < e; s += BLOCK) {
-        uint32_t id = ids[s];
-        uint64_t car = static_cast<uint64_t>(car_begin) + id;
-        double ub, uc;
-        if (ABL & 2) {
-            ub = (id * 2654435761u) * 0x1.0p-32;
-            uc = ((id ^ step) * 2246822519u) * 0x1.0p-32;
-        } else {
-            car_uniforms(seed, car, step, 0, ub, uc);
-        }
-        bool drive = ub <= pd;
-        uint32_t dest = z;
-        if (drive) {
-            if (ABL & 1) dest = static_cast<uint32_t>(uc * Z);
-            else if (last != 0.0) dest = static_cast<uint32_t>(lower_bound_row(row, Z, clamp_u(uc, last)));
-            if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest, seed, car, step);
-            ++nd;
-        }
-        dest_out[s] = dest | (drive ? kDriveBit : 0u);
-    }
-    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
-    if ((tid & 63) == 0 && nd) atomicAdd(&s_ndrive, nd);
-    if (TRAVEL) {
-        for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
-        if ((tid & 63) == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
-    }
-    __syncthreads();
-    if (tid == 0) {
-        driving_t[z] = s_ndrive;
-        if (TRAVEL && s_tt) atomicAdd(tt_sum, s_tt);
-    }
-}
-
-// Second form of the zone sampler (the default): same contract as k_zone_sample, plus
+// The zone sampler of the exact layout:
 //   * the car ids of the bucket are requested BEFORE the row (vmcnt retires in order: by the time
 //     the row has landed and the barrier has passed they are there, instead of one exposed HBM
 //     round trip per round of cars);
@@ -108,22 +43,20 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample(
 //   * Bernoulli draw in integers (k <= floor(p * 2^53)).
 // NP: 16-B row pieces per thread (>= Zp / 2 / BLOCK).
 template <bool TRAVEL, int BLOCK, int NP, int CPT>
-__global__ __launch_bounds__(BLOCK) void k_zone_sample2(
+__global__ __launch_bounds__(BLOCK) void k_exact_sample(
     const uint32_t *__restrict__ ids, const uint32_t *__restrict__ off, uint32_t *__restrict__ dest_out,
-    const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int H, int64_t car_begin,
+    const double *__restrict__ pdrive_t, const double *__restrict__ cdf_t, int Z, int Zp, int H, CarIndex cars,
     uint32_t step, uint64_t seed, unsigned long long *__restrict__ parking_t,
     unsigned long long *__restrict__ driving_t, const double *__restrict__ dm, int T, int t,
-    unsigned long long *tt_sum, uint32_t cap)
+    unsigned long long *tt_sum)
 {
     extern __shared__ double row[];  // 2^H doubles: the zone's CDF row as a search tree
     __shared__ uint32_t s_ndrive;
     __shared__ unsigned long long s_tt;
     const int z = blockIdx.x;
     const int tid = threadIdx.x;
-    // cap == 0: exact layout, bucket z = [off[z], off[z+1]).  cap > 0: fixed-stride layout, bucket z =
-    // [z*cap, z*cap + off[z]) (off[] holds the bucket sizes).
-    const uint32_t b = cap ? static_cast<uint32_t>(z) * cap : off[z];
-    const uint32_t n = cap ? min(off[z], cap) : off[z + 1] - b;  // (an overflowed bucket is flagged by the sort; stay in range)
+    const uint32_t b = off[z];  // bucket z = [off[z], off[z+1])
+    const uint32_t n = off[z + 1] - b;
     const uint32_t e = b + n;
     if (tid == 0) {
         parking_t[z] = n;  // every car present at hour t, drivers included (Appendix A-14)
@@ -168,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample2(
             valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
             long long kb;
             double uc;
-            car_draws(seed, static_cast<uint64_t>(car_begin) + id[c], step, kb, uc);
+            car_draws(seed, cars.global(id[c]), step, kb, uc);
             drive[c] = valid[c] && (kb <= thr);
             dest[c] = z;
             ue[c] = clamp_u(uc, last);
@@ -194,13 +127,13 @@ __global__ __launch_bounds__(BLOCK) void k_zone_sample2(
             if (valid[c]) dest_out[b + tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
             if (drive[c]) {
                 ++nd;
-                if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest[c], seed, static_cast<uint64_t>(car_begin) + id[c], step);
+                if (TRAVEL) tt += travel_time_q16(dm, Z, T, t, z, dest[c], seed, cars.global(id[c]), step);
             }
         }
     }
     for (uint32_t s = b + CPT * BLOCK + tid; s < e; s += BLOCK) {  // buckets larger than CPT*BLOCK cars
         const uint32_t idx = (s < b + (CPT + 1) * BLOCK) ? id_x : ids[s];
-        const uint64_t car = static_cast<uint64_t>(car_begin) + idx;
+        const uint64_t car = cars.global(idx);
         long long kb;
         double uc;
         car_draws(seed, car, step, kb, uc);
@@ -280,7 +213,6 @@ __device__ __forceinline__ uint32_t wave_slot_take(uint32_t *pos, uint32_t keyfl
 // key is 16-B aligned: 16 B per lane per load, all of a thread's loads issued before its atomics.
 constexpr int kSortUnroll = 4;
 
-template <int ABL>
 __global__ __launch_bounds__(kSortBlock) void k_zone_hist(const uint32_t *__restrict__ key, int64_t n, int Z,
                                                           int64_t chunk, uint32_t *__restrict__ cursor,
                                                           uint32_t *__restrict__ base)
@@ -332,7 +264,6 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_hist(const uint32_t *__rest
 }
 
 // counting sort pass 2.  ids == nullptr: slot index is the car id (initial bucketing).
-template <int ABL>
 __global__ __launch_bounds__(kSortBlock) void k_zone_scatter(const uint32_t *__restrict__ key,
                                                              const uint32_t *__restrict__ ids, int64_t n, int Z,
                                                              int64_t chunk, const uint32_t *__restrict__ cursor,
@@ -408,25 +339,15 @@ __global__ __launch_bounds__(kSortBlock) void k_zone_scatter(const uint32_t *__r
 #pragma unroll
         for (int u = 0; u < kSortUnroll; ++u) {
             const bool ok = j + u * kSortBlock < n4;
-            uint32_t p0, p1, p2, p3;
-            if (ABL & 16) {
-                p0 = static_cast<uint32_t>(i0 + 4 * (j + u * kSortBlock));
-                p1 = p0 + 1; p2 = p0 + 2; p3 = p0 + 3;
-            } else {
-                p0 = wave_slot_take(pos, v[u].x, ok);
-                p1 = wave_slot_take(pos, v[u].y, ok);
-                p2 = wave_slot_take(pos, v[u].z, ok);
-                p3 = wave_slot_take(pos, v[u].w, ok);
-            }
+            const uint32_t p0 = wave_slot_take(pos, v[u].x, ok);
+            const uint32_t p1 = wave_slot_take(pos, v[u].y, ok);
+            const uint32_t p2 = wave_slot_take(pos, v[u].z, ok);
+            const uint32_t p3 = wave_slot_take(pos, v[u].w, ok);
             if (ok) {
-                if (ABL & 8) {
-                    if (p0 + p1 + p2 + p3 == 0xdeadbeefu) ids_next[0] = c[u].x + c[u].y + c[u].z + c[u].w;
-                } else {
-                    ids_next[p0] = c[u].x;
-                    ids_next[p1] = c[u].y;
-                    ids_next[p2] = c[u].z;
-                    ids_next[p3] = c[u].w;
-                }
+                ids_next[p0] = c[u].x;
+                ids_next[p1] = c[u].y;
+                ids_next[p2] = c[u].z;
+                ids_next[p3] = c[u].w;
             }
         }
     }
@@ -443,12 +364,9 @@ __global__ void k_zone_unbucket(const uint32_t *__restrict__ ids, const uint32_t
     for (uint32_t s = off[z] + threadIdx.x; s < off[z + 1]; s += blockDim.x) zone0[ids[s]] = z;
 }
 
-struct ZoneWork {
+struct ExactWork {
     bool tables_dirty = true;
     bool buckets0_valid = false;  // ids0/off0 describe the context's current car state
-    int block = 512;              // workgroup size of k_zone_sample (tuning knob; 512 measured best at Z = 4096)
-    int ablate = 0;               // diagnostic: see k_zone_sample ABL
-    bool tree = true;             // k_zone_sample2 (tree layout) instead of k_zone_sample (sorted row)
     int64_t n = 0;
     int Z = 0, T = 0, nb = 0;
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [n]
@@ -493,67 +411,74 @@ struct ZoneWork {
     }
 };
 
-struct ZoneWork;
-inline size_t zone_sample_lds(int Zp) { return sizeof(double) * static_cast<size_t>(Zp); }
-
-// true when the zone path can run this problem (LDS row + sort bins must fit a CU's 160 KiB)
-inline bool zone_path_fits(int Zp)
+// true when the path can run this problem (the row as a search tree, and the sort bins, must fit a CU's 160 KiB of LDS)
+inline bool exact_path_fits(int Z)
 {
-    return sizeof(double) * (size_t(1) << tree_height(Zp)) + 64 <= 160 * 1024 && zone_sample_lds(Zp) + 64 <= 160 * 1024;
+    return sizeof(double) * (size_t(1) << tree_height(Z)) + 64 <= 160 * 1024 && sizeof(uint32_t) * static_cast<size_t>(Z) + 1024 <= 160 * 1024;
 }
 
-#define CPM_ZS_ARGS ids, off, w.dest, pd, cdf, Z, Zp, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum
-
-template <int BLOCK, int ABL>
-inline void launch_zone_sample_b(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
-                                 const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
-                                 uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
-                                 const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row)
+// two cars per thread (measured at S4k: 1 -> 38.8 us, 2 -> 36.4, 3 -> 38.5, 4 -> 44.4), 512 threads
+template <bool TRAVEL, int NP>
+inline void exact_launch_np(hipStream_t stream, size_t lds_tree, const uint32_t *ids, const uint32_t *off, uint32_t *dest_out, const double *pd,
+                            const double *cdf, int Z, int Zp, int H, CarIndex cars, uint32_t step, uint64_t seed,
+                            unsigned long long *parking_t, unsigned long long *driving_t, const double *dm, int T, int t,
+                            unsigned long long *tt_sum)
 {
-    if (travel)
-        hipLaunchKernelGGL((k_zone_sample<true, BLOCK, ABL>), dim3(Z), dim3(BLOCK), lds_row, stream, CPM_ZS_ARGS);
-    else
-        hipLaunchKernelGGL((k_zone_sample<false, BLOCK, ABL>), dim3(Z), dim3(BLOCK), lds_row, stream, CPM_ZS_ARGS);
+    if (lds_tree > 48 * 1024) {  // LDS opt-in, once per device
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_sample<TRAVEL, 512, NP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_exact_sample<TRAVEL, 512, NP, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, cdf, Z, Zp, H, cars, step,
+                       seed, parking_t, driving_t, dm, T, t, tt_sum);
 }
 
-inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
-                               const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
-                               uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
-                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row,
-                               uint32_t *dest_out = nullptr, uint32_t cap = 0);
+template <bool TRAVEL>
+inline void exact_launch_sample(hipStream_t stream, const uint32_t *ids, const uint32_t *off, uint32_t *dest_out, const double *pd, const double *cdf,
+                                int Z, int Zp, CarIndex cars, uint32_t step, uint64_t seed, unsigned long long *parking_t,
+                                unsigned long long *driving_t, const double *dm, int T, int t, unsigned long long *tt_sum)
+{
+    const int H = tree_height(Z);
+    const size_t lds_tree = sizeof(double) * (size_t(1) << H);
+    const int need = (Zp / 2 + 511) / 512;
+#define CPM_EXACT_ARGS stream, lds_tree, ids, off, dest_out, pd, cdf, Z, Zp, H, cars, step, seed, parking_t, driving_t, dm, T, t, tt_sum
+    if (need <= 1) exact_launch_np<TRAVEL, 1>(CPM_EXACT_ARGS);
+    else if (need <= 2) exact_launch_np<TRAVEL, 2>(CPM_EXACT_ARGS);
+    else if (need <= 4) exact_launch_np<TRAVEL, 4>(CPM_EXACT_ARGS);
+    else if (need <= 8) exact_launch_np<TRAVEL, 8>(CPM_EXACT_ARGS);
+    else exact_launch_np<TRAVEL, 16>(CPM_EXACT_ARGS);
+#undef CPM_EXACT_ARGS
+}
 
 // ivp == false: the T-hour resample from the state in d_zone0 (left unchanged); counts -> d_counts.
 // ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps
 //               0..T-2, every transition applied; the final buckets become the cached bucketing of
 //               the new state and are written back car-indexed into d_zone0_out.  d_counts is scratch.
 template <typename F1, typename F2>
-int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T,
-                      int64_t n, int64_t car_begin, const uint32_t *d_zone0, uint64_t seed, bool travel,
-                      const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err,
-                      bool ivp = false, uint32_t *d_zone0_out = nullptr)
+int32_t exact_run(ExactWork &w, hipStream_t stream, const double *d_pdrive, const double *d_cdf, int Z, int Zp, int T, int64_t n, CarIndex cars,
+                  const uint32_t *d_zone0, uint64_t seed, bool travel, const double *d_dm, int64_t *d_counts, int cu_count, F1 prof_begin,
+                  F2 prof_end, std::string &err, bool ivp = false, uint32_t *d_zone0_out = nullptr)
 {
     auto hip_fail = [&](hipError_t e, const char *what) {
         err = std::string(what) + ": " + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
     };
-    if (!zone_path_fits(Zp)) {
+    if (!exact_path_fits(Z)) {
         err = "CPM_KERNEL_ZONE_LDS: a CDF row of this many zones does not fit in LDS (use CPM_KERNEL_CAR)";
         return CPM_ERR_ARG;
     }
     hipError_t e = w.ensure(n, Z, T, cu_count);
     if (e != hipSuccess) return hip_fail(e, "zone workspace");
-    const size_t lds_row = zone_sample_lds(Zp), lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
-    if (w.tables_dirty) {  // LDS opt-in above 64 KiB, once per context / table size
-        if (lds_row > 64 * 1024) {
-            const void *fns[] = {reinterpret_cast<const void *>(k_zone_sample<false, 256, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 256, 0>),
-                                 reinterpret_cast<const void *>(k_zone_sample<false, 512, 0>), reinterpret_cast<const void *>(k_zone_sample<true, 512, 0>)};
-            for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_row));
-        }
-        if (lds_bins > 64 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_hist<0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_scatter<0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
+    const size_t lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
+    if (w.tables_dirty) {  // LDS opt-in above 48 KiB, once per context
+        if (lds_bins > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_hist), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
         }
         w.tables_dirty = false;
     }
@@ -563,9 +488,9 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
     if (e != hipSuccess) return hip_fail(e, "memset cursor");
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         uint32_t *cur0 = w.cursor + static_cast<size_t>(T) * Z;
-        hipLaunchKernelGGL(k_zone_hist<0>, sgrid, sblock, lds_bins, stream, d_zone0, n, Z, chunk, cur0, w.base);
-        hipLaunchKernelGGL(k_zone_scatter<0>, sgrid, sblock, lds_bins, stream, d_zone0, static_cast<const uint32_t *>(nullptr),
-                           n, Z, chunk, cur0, w.base, w.ids0, w.off0);
+        hipLaunchKernelGGL(k_zone_hist, sgrid, sblock, lds_bins, stream, d_zone0, n, Z, chunk, cur0, w.base);
+        hipLaunchKernelGGL(k_zone_scatter, sgrid, sblock, lds_bins, stream, d_zone0, static_cast<const uint32_t *>(nullptr), n, Z, chunk, cur0, w.base,
+                           w.ids0, w.off0);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
         w.buckets0_valid = true;
     }
@@ -577,19 +502,21 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
     for (int t = 0; t < hours; ++t) {
         const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
         const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
-        uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
+        const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
         prof_begin(t);
-        launch_zone_sample(w, stream, travel, ids, off, pd, cdf, Z, Zp, car_begin, step, seed,
-                           parking + static_cast<size_t>(t) * Z, driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum,
-                           lds_row);
+        if (travel)
+            exact_launch_sample<true>(stream, ids, off, w.dest, pd, cdf, Z, Zp, cars, step, seed, parking + static_cast<size_t>(t) * Z,
+                                      driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum);
+        else
+            exact_launch_sample<false>(stream, ids, off, w.dest, pd, cdf, Z, Zp, cars, step, seed, parking + static_cast<size_t>(t) * Z,
+                                       driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum);
         prof_end(t);
         if (ivp || t + 1 < T) {  // resampling: hour T's transition is sampled but never applied (src/resampling.jl:81-83)
             uint32_t *cur = w.cursor + static_cast<size_t>(t) * Z;
             uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
             uint32_t *off_next = (t & 1) ? w.offB : w.offA;
-            hipLaunchKernelGGL(k_zone_hist<0>, sgrid, sblock, lds_bins, stream, w.dest, n, Z, chunk, cur, w.base);
-            hipLaunchKernelGGL(k_zone_scatter<0>, sgrid, sblock, lds_bins, stream, w.dest, ids, n, Z, chunk, cur, w.base,
-                               ids_next, off_next);
+            hipLaunchKernelGGL(k_zone_hist, sgrid, sblock, lds_bins, stream, w.dest, n, Z, chunk, cur, w.base);
+            hipLaunchKernelGGL(k_zone_scatter, sgrid, sblock, lds_bins, stream, w.dest, ids, n, Z, chunk, cur, w.base, ids_next, off_next);
             ids = ids_next;
             off = off_next;
         }
@@ -599,8 +526,7 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
         // the final buckets describe the new state: keep them as the cached initial bucketing and
         // write the state back car-indexed (initial_state of src/solveinitialvalueproblem.jl:57-58)
         if (ids != w.ids0) {
-            if ((e = hipMemcpyAsync(w.ids0, ids, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
-                return hip_fail(e, "copy buckets");
+            if ((e = hipMemcpyAsync(w.ids0, ids, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return hip_fail(e, "copy buckets");
             if ((e = hipMemcpyAsync(w.off0, off, sizeof(uint32_t) * (Z + 1), hipMemcpyDeviceToDevice, stream)) != hipSuccess)
                 return hip_fail(e, "copy offsets");
         }
@@ -609,62 +535,6 @@ int32_t zone_resample(ZoneWork &w, hipStream_t stream, const double *d_pdrive, c
         w.buckets0_valid = true;
     }
     return CPM_OK;
-}
-
-#define CPM_ZS_CALL(B, A) \
-    launch_zone_sample_b<B, A>(w, stream, travel, ids, off, pd, cdf, Z, Zp, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, lds_row)
-
-inline void launch_zone_sample(ZoneWork &w, hipStream_t stream, bool travel, const uint32_t *ids, const uint32_t *off,
-                               const double *pd, const double *cdf, int Z, int Zp, int64_t car_begin, uint32_t step,
-                               uint64_t seed, unsigned long long *parking_t, unsigned long long *driving_t,
-                               const double *dm, int T, int t, unsigned long long *tt_sum, size_t lds_row,
-                               uint32_t *dest_out, uint32_t cap)
-{
-    if (!dest_out) dest_out = w.dest;
-#ifdef CPM_DIAGNOSTIC
-    if (w.ablate & 7) {  // diagnostic ablations, 256-thread form only
-        switch (w.ablate & 7) {
-        case 1: CPM_ZS_CALL(256, 1); break;
-        case 2: CPM_ZS_CALL(256, 2); break;
-        case 3: CPM_ZS_CALL(256, 3); break;
-        case 4: CPM_ZS_CALL(256, 4); break;
-        default: CPM_ZS_CALL(256, 7); break;
-        }
-        return;
-    }
-#endif
-    if (w.tree) {  // default: tree layout, id prefetch, two cars per thread (measured at S4k: 1 -> 38.8 us, 2 -> 36.4, 3 -> 38.5, 4 -> 44.4)
-        const int H = tree_height(Z);
-        const size_t lds_tree = sizeof(double) * (size_t(1) << H);
-        const int need = (Zp / 2 + 511) / 512;
-#define CPM_ZS2(NPV)                                                                                                     \
-    do {                                                                                                                 \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done && lds_tree > 64 * 1024) {                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<false, 512, NPV, 2>),              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_zone_sample2<true, 512, NPV, 2>),               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
-            attr_done = true;                                                                                            \
-        }                                                                                                                \
-        if (travel)                                                                                                      \
-            hipLaunchKernelGGL((k_zone_sample2<true, 512, NPV, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
-                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
-        else                                                                                                             \
-            hipLaunchKernelGGL((k_zone_sample2<false, 512, NPV, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, \
-                               cdf, Z, Zp, H, car_begin, step, seed, parking_t, driving_t, dm, T, t, tt_sum, cap);      \
-    } while (0)
-        if (need <= 1) CPM_ZS2(1);
-        else if (need <= 2) CPM_ZS2(2);
-        else if (need <= 4) CPM_ZS2(4);
-        else if (need <= 8) CPM_ZS2(8);
-        else CPM_ZS2(16);
-        return;
-    }
-    switch (w.block) {
-    case 512: CPM_ZS_CALL(512, 0); break;
-    default: CPM_ZS_CALL(256, 0); break;
-    }
 }
 
 }  // namespace cpm

@@ -1,0 +1,1054 @@
+// cpm_grouped.h -- CPM_KERNEL_ZONE_GROUPED, the path CPM_KERNEL_AUTO runs: the hourly step of src/resampling.jl:11-49,81-83 (and of
+// src/solveinitialvalueproblem.jl:8-53) with the cars kept bucketed by origin zone.
+//
+// The reference walks p_dest[origin,:,t] once per driving car (src/resampling.jl:34-45).  Here the cars of one origin zone sit
+// together, so the zone's row is streamed from HBM once per hour into LDS and every car of the zone searches it there.
+//
+//   * Fixed-stride buckets: zone z owns ids[z*cap .. z*cap + cnt[z]) (cap = cap_mult x the mean bucket, cap_mult = 4, doubled by the
+//     context after an overflow).  The bucket sizes ARE the parking histogram (src/saveresults.jl:10-12): no histogram atomics.
+//   * Row packs: what a workgroup stages is the HIGH WORD of the canonical CDF row (4 B per destination instead of 8) behind a GUIDE
+//     table (cut-point method).  With hi[j] = floor(cdf[j] * 2^32) (0xFFFFFFFF when cdf[j] >= 1) and khi = the high Philox word
+//     = floor(u * 2^32):   hi[j] > khi => cdf[j] >= u   and   hi[j-1] < khi => cdf[j-1] < u,   so the first j with hi[j] >= khi IS
+//     the reference's answer (first j with u <= cdf[j], :38-45) whenever hi[j] > khi strictly.  On a tie (probability ~ Z * 2^-32
+//     per draw), or when u lies above the row total, the car repeats the search on the f64 row in HBM (clamp_u + lower_bound_row,
+//     the code of the other kernels).  Bit-identical to the f64 search by construction; cpm_debug_categorical and
+//     tests/test_gpu_parity.py::test_high_word_search_* drive the tie, saturation and out-of-range branches.
+//     guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G (u16, clamped to Z - 1; G = ceil(log2 Z) - 2).
+//     A row pack = [2^G + 8 u16 guide][Zq u32 hi], Zq = Z + at least 31 entries of 0xFFFFFFFF, rounded to 32.
+//   * Stayers (about half the cars) never leave their zone: the sampler compacts them into the zone's region of next hour's id
+//     array.  Drivers go into FIXED-SIZE runs, one per (origin zone, destination group) -- 32 groups of 2^gshift consecutive
+//     zones -- at D[(z*32 + g)*scap + rank], rank from an LDS atomic, as id | (dest mod 2^gshift) << idbits.  k_grouped_place
+//     then moves every group's drivers into their buckets; its blocks of one group share an XCD (one L2), where the 4-byte id
+//     writes to a bucket merge before they leave.
+//   * A bucket that would outgrow cap, or a run that would outgrow scap, raises the status word (no out-of-range store is issued);
+//     the context doubles its regions and the step is repeated (cpm_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/cpm.h"
+#include "cpm_kernels.h"
+
+namespace cpm {
+
+constexpr int kGroups = 32;              // destination groups
+constexpr int kMaxZonesPerGroup = 1024;  // LDS bins of the place kernel
+constexpr uint32_t kHiMax = 0xFFFFFFFFu;
+constexpr int kMaxCapMult = 64;
+
+// ------------------------------------------------------------------------------------------------ row packs
+__host__ __device__ inline int pack_guide_bits(int Z)
+{
+    int g = 3;  // >= 8 entries: the guide is a whole number of 16-B pieces
+    while ((1 << g) < Z) ++g;
+    // a quarter of an entry per destination: measured best at S4k (entries per destination 1: 32.0 us, 1/2: 29.9, 1/4: 29.1 --
+    // the shorter pack outweighs the longer bracket)
+    g = g - 2 < 3 ? 3 : g - 2;
+    return g;
+}
+// high words per row: Z, then at least 31 entries of 0xFFFFFFFF (the unclamped stride walk of pack_search reads up to 30 past
+// its bracket), a whole number of 128-B lines
+__host__ __device__ inline int pack_zq(int Z) { return (Z + 31 + 31) / 32 * 32; }
+__host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4; }  // 2^G + 1 entries used (+7 pad: whole 16-B pieces)
+__host__ __device__ inline int pack_row_words(int Zq, int G)  // at least 1 KiB: one whole LDS-DMA wave-instruction
+{
+    const int w = pack_guide_words(G) + Zq;
+    return w < 256 ? 256 : w;
+}
+// a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
+inline bool pack_row_fits(int Z)
+{
+    if (Z < 2 || Z > 32768) return false;
+    return sizeof(uint32_t) * static_cast<size_t>(pack_row_words(pack_zq(Z), pack_guide_bits(Z))) <= 150 * 1024;
+}
+
+// hi part of every row pack and last[t][o], from the canonical CDF (one thread per element, coalesced both ways)
+__global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ cdf, uint32_t *__restrict__ rp, double *__restrict__ last,
+                                                    int Z, int Zp, int Zq, int G, int64_t rows)
+{
+    const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
+    if (row >= rows) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Zq) return;
+    uint32_t h = kHiMax;
+    if (j < Z) {
+        const double c = cdf[row * Zp + j];
+        if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated by k_build_cdf)
+        if (j == Z - 1) last[row] = c;
+    }
+    rp[row * pack_row_words(Zq, G) + pack_guide_words(G) + j] = h;
+}
+
+// thr[t][z] = bernoulli_threshold(p_drive[t][z]): the integer the sampler compares the 53-bit draw with (src/resampling.jl:15 as
+// k <= floor(p * 2^53); one scalar load per workgroup instead of f64 arithmetic in every thread)
+__global__ __launch_bounds__(256) void k_build_thr(const double *__restrict__ pdrive, long long *__restrict__ thr, int64_t n)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) thr[i] = bernoulli_threshold(pdrive[i]);
+}
+
+// guide part: guide[m] = min(first j in [0, Z) with hi[j] >= m << (32 - G), Z - 1), m = 0 .. 2^G (entry 2^G and the pad: Z - 1)
+__global__ __launch_bounds__(256) void k_build_guide(uint32_t *__restrict__ rp, int Z, int Zq, int G, int64_t rows)
+{
+    const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
+    if (row >= rows) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= (1 << G) + 8) return;
+    uint32_t *pack = rp + row * pack_row_words(Zq, G);
+    const uint32_t *hi = pack + pack_guide_words(G);
+    int lo = Z - 1;
+    if (m < (1 << G)) {
+        const uint32_t edge = static_cast<uint32_t>(m) << (32 - G);
+        int n = Z;
+        lo = 0;
+        while (n > 0) {
+            const int half = n >> 1;
+            if (hi[lo + half] < edge) {
+                lo += half + 1;
+                n -= half + 1;
+            } else {
+                n = half;
+            }
+        }
+        lo = min(lo, Z - 1);
+    }
+    reinterpret_cast<uint16_t *>(pack)[m] = static_cast<uint16_t>(lo);
+}
+
+// ------------------------------------------------------------------------------------------------ bucketing
+// Car-indexed state -> fixed-stride buckets (once per state; cached until the state changes): LDS histogram of the zones of this
+// block's cars -> one batched round of global atomics reserves the block's range in every bucket -> ids move to zone*cap + position.
+constexpr int kBucketBlock = 1024;
+constexpr int kBucketMaxPass = 512;  // 1024-car passes per block
+
+__global__ __launch_bounds__(kBucketBlock) void k_bucket_cars(const uint32_t *__restrict__ zone0, int64_t n, int64_t chunk, int Z, uint32_t cap,
+                                                              uint32_t *__restrict__ cnt, uint32_t *__restrict__ ids, unsigned long long *status)
+{
+    extern __shared__ uint32_t bins[];  // Z: histogram, then running position inside each bucket
+    const int tid = threadIdx.x;
+    for (int z = tid; z < Z; z += kBucketBlock) bins[z] = 0;
+    __syncthreads();
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * chunk, i1 = min(i0 + chunk, n);
+    constexpr int kU = 8;  // passes in flight per thread: all their loads are issued before the first use
+    for (int64_t p0 = i0; p0 < i1; p0 += static_cast<int64_t>(kU) * kBucketBlock) {
+        uint32_t v[kU];
+        bool ok[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int64_t i = p0 + static_cast<int64_t>(u) * kBucketBlock + tid;
+            ok[u] = i < i1;
+            if (ok[u]) v[u] = zone0[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (ok[u]) atomicAdd(&bins[v[u] & kZoneMask], 1u);
+    }
+    __syncthreads();
+    for (int zb = 0; zb < Z; zb += kBucketBlock * 4) {  // ticket: bins[z] becomes this block's first position inside bucket z
+        uint32_t r[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + tid + k * kBucketBlock;
+            r[k] = 0;
+            c[k] = 0;
+            if (z < Z) {
+                c[k] = bins[z];
+                if (c[k]) r[k] = atomicAdd(&cnt[z], c[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = zb + tid + k * kBucketBlock;
+            if (z < Z) {
+                bins[z] = r[k];
+                if (r[k] + c[k] > cap) atomicOr(status, 2ull);  // bucket outgrew its region: step invalid
+            }
+        }
+    }
+    __syncthreads();
+    for (int64_t p0 = i0; p0 < i1; p0 += static_cast<int64_t>(kU) * kBucketBlock) {  // (zones re-read: L2-resident from the histogram pass)
+        uint32_t v[kU];
+        bool ok[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int64_t i = p0 + static_cast<int64_t>(u) * kBucketBlock + tid;
+            ok[u] = i < i1;
+            if (ok[u]) v[u] = zone0[i] & kZoneMask;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (ok[u]) {
+                const uint32_t p = atomicAdd(&bins[v[u]], 1u);
+                if (p < cap) ids[static_cast<size_t>(v[u]) * cap + p] = static_cast<uint32_t>(p0 + static_cast<int64_t>(u) * kBucketBlock + tid);
+            }
+    }
+}
+
+// car-indexed state from fixed-stride buckets (end of the IVP)
+__global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t *__restrict__ zone0)
+{
+    const uint32_t z = blockIdx.x;
+    const uint32_t n = min(cnt[z], cap);
+    for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) zone0[ids[static_cast<size_t>(z) * cap + s]] = z;
+}
+
+// ------------------------------------------------------------------------------------------------ hourly sampler
+struct GroupedArgs {
+    const uint32_t *ids;      // [Z*cap] this hour's buckets (local car indices)
+    const uint32_t *cnt;      // [Z] their sizes
+    const uint32_t *rp_t;     // [Z][RW] row packs of this hour
+    const double *last_t;     // [Z] row totals (f64)
+    const long long *thr_t;   // [Z] Bernoulli thresholds floor(p_drive * 2^53) of this hour
+    const double *cdf_t;      // [Z][Zp] canonical CDF rows of this hour (exact fallback)
+    uint32_t *ids_next;       // [Z*cap]  next hour's buckets: the stayers (grouped) / dest | drive << 31 per slot (plain)
+    uint32_t *cnt_next;       // [Z] stayers (grouped; k_grouped_place adds the arrivals)
+    uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
+    uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
+    unsigned long long *parking_t, *driving_t, *status;
+    int Z, Zp, Zq, G;
+    uint32_t cap, scap, idbits, gshift, step;
+    CarIndex cars;
+    uint64_t seed;
+};
+
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+
+// Row pack -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR destination, no ds_write; one wave-instruction moves
+// 64 x 16 B to 1 KiB of consecutive LDS.  The destination is wave-uniform base + lane x 16, the source is per lane.
+// Counts in vmcnt like any load.  Every wave issues exactly NQ instructions, unpredicated (so that the count is known at
+// compile time and the wave can wait for its OLDER id loads alone with s_waitcnt vmcnt(NQ)): chunk k = 64 pieces from
+// min(64 k, pieces - 64); chunks past the end repeat the last one (same bytes to the same LDS words).  pieces >= 64.
+template <int BLOCK, int NQ>
+__device__ __forceinline__ void pack_dma(uint32_t *lds, const uint32_t *pack, int pieces, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+        const int p0 = min((m * (BLOCK / 64) + wave) * 64, pieces - 64);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(pack) + p0 + lane,
+                                         (__attribute__((address_space(3))) void *)(lds + 4 * p0), 16, 0, 0);
+    }
+}
+
+// s_waitcnt vmcnt(NQ) carrying the id registers as in/out operands: no use of an id can move above it
+template <int N, int NQ>
+__device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
+{
+    static_assert((N == 2 || N == 3 || N == 5) && NQ <= 63, "written for CPT = 1, 2, 4");
+    if constexpr (N == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]) : "n"(NQ) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]) : "n"(NQ) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(id[0]), "+v"(id[1]) : "n"(NQ) : "memory");
+}
+
+// The f64 search of the other kernels, on the row where it lies in HBM (rare: ties and u above the row total).
+__device__ __noinline__ uint32_t search_exact_row(const double *__restrict__ cdf_row, int Z, double uc, double last)
+{
+    return static_cast<uint32_t>(lower_bound_row(cdf_row, Z, clamp_u(uc, last)));
+}
+
+// CPT draws against the staged pack, in lockstep (CPT independent LDS reads in flight per step):
+// dest[c] = first j with hi[j] >= khi[c], ok[c] = the answer is certain (hi[dest] > khi).  want[c] == false: no search.
+// The guide brackets the answer: j in [L, L + n], L = guide[m], n = guide[m+1] - L, m = khi >> sh (entries are clamped to Z-1
+// and a draw above the row's last high word never searches, so the bracket is in range).  hi[] is non-decreasing over the WHOLE
+// row and padded with 0xFFFFFFFF for >= 31 entries past Z-1 (Zq), so the lower bound inside the bracket is a descending-stride
+// walk that needs no upper clamp: with 2^K > n,  for s = 2^(K-1) .. 1:  if (hi[L + o + s - 1] < khi) o += s  ends at o = the
+// number of entries from L on that lie below khi = the answer's offset (<= n <= 2^K - 1; the largest index read is L + 2^K - 2).
+// K is wave-uniform (the widest bracket among the wave's draws decides): three to five steps of
+// {LDS read, compare, select, add} on the dense synthetic rows.  Brackets of 32 entries and more (rows with long runs of
+// zero-probability zones) take the same walk from a larger K with the probe index clamped to the row.
+template <int CPT>
+__device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint32_t *hi_g, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
+                                            int sh, uint32_t hi_last, int Zq, uint32_t (&dest)[CPT], bool (&ok)[CPT])
+{
+    lds_cu16 *guide = (lds_cu16 *)guide_g;
+    lds_cu32 *hi = (lds_cu32 *)hi_g;
+    uint32_t kk[CPT], lo[CPT], n[CPT], nor = 0;
+    bool in[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        in[c] = want[c] & (khi[c] <= hi_last);
+        kk[c] = in[c] ? khi[c] : 0u;  // (a draw that does not search never moves: nothing is below 0)
+        const uint32_t m = kk[c] >> sh;
+        lo[c] = guide[m];
+        n[c] = guide[m + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        n[c] = in[c] ? n[c] - lo[c] : 0u;
+        nor |= n[c];
+    }
+    if (__builtin_expect(__any(nor >= 32u), 0)) {  // wave-uniform
+        int K = 6;
+        while (__any((nor >> K) != 0u)) ++K;
+        for (uint32_t s = 1u << (K - 1); s != 0u; s >>= 1) {
+            uint32_t v[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) v[c] = hi[min(lo[c] + s - 1u, static_cast<uint32_t>(Zq - 1))];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) lo[c] += (v[c] < kk[c]) ? s : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            dest[c] = lo[c];
+            ok[c] = in[c] & (hi[lo[c]] > kk[c]);
+        }
+        return;
+    }
+    lds_cu32 *p[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) p[c] = hi + lo[c];
+#define CPM_PACK_STEP(S)                                                                    \
+    do {                                                                                    \
+        uint32_t v_[CPT];                                                                   \
+        _Pragma("unroll") for (int c = 0; c < CPT; ++c) v_[c] = p[c][(S) - 1];              \
+        _Pragma("unroll") for (int c = 0; c < CPT; ++c) p[c] += (v_[c] < kk[c]) ? (S) : 0;  \
+    } while (0)
+    const bool a16 = __any(nor >= 16u);
+    const bool a8 = a16 || __any(nor >= 8u);
+    if (a16) CPM_PACK_STEP(16);
+    if (a8) CPM_PACK_STEP(8);
+    CPM_PACK_STEP(4);
+    CPM_PACK_STEP(2);
+    CPM_PACK_STEP(1);
+#undef CPM_PACK_STEP
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {  // (LDS addresses are 32 bits wide: a plain pointer difference would be done in 64)
+        const uint32_t fin = p[c][0];
+        dest[c] = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p[c])) - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(hi))) >> 2;
+        ok[c] = in[c] & (fin > kk[c]);
+    }
+}
+
+// Philox words of (car, step, stream 0): Bernoulli integer kb (53 bits of words 0,1) and the categorical words (2,3)
+__device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint32_t step, long long &kb, uint32_t &clo, uint32_t &chi)
+{
+    U4 r = philox4x32_10(static_cast<uint32_t>(car), static_cast<uint32_t>(car >> 32), step, 0u, static_cast<uint32_t>(seed),
+                         static_cast<uint32_t>(seed >> 32));
+    kb = static_cast<long long>(((static_cast<uint64_t>(r.y) << 32) | r.x) >> 11);
+    clo = r.z;
+    chi = r.w;
+}
+
+// One workgroup per origin zone.  (Resident workgroups each walking several zones, with or without the next zone's registers or
+// pack prefetched, were measured no faster; profiles/round1_notes.md.)
+// GROUPED: stayers compacted into next hour's bucket of the zone, drivers into the zone's fixed-size runs.  The drivers are
+//          first ranked and staged in LDS (kStage entries per group) and written out by 16 lanes per run, 64 B at a time;
+//          ranks beyond kStage go to HBM directly.
+// !GROUPED: dest | drive << 31 per slot into ids_next (hour T of a resample: sampled, never applied, src/resampling.jl:81-83).
+// Order of a workgroup's life: the bucket size, the threshold, the ids and the row pack are requested together (the id loads are
+// clamped to the zone's REGION, not to its size, so they do not wait for the size); Philox runs while the pack is landing;
+// after the barrier the CPT cars of a thread search in lockstep and take their slots with one stayer ticket per wave and CPT
+// rank atomics in flight together.
+#ifndef CPM_STAGE
+#define CPM_STAGE 32
+#endif
+constexpr int kStage = CPM_STAGE;
+#ifndef CPM_WPS
+#define CPM_WPS 6  // waves per SIMD the register allocator must leave room for (see profiles/round1_notes.md, round2_notes.md)
+#endif
+
+template <int BLOCK, int CPT, int NQ, bool GROUPED>
+__global__ __launch_bounds__(BLOCK, CPM_WPS) void k_grouped_sample(GroupedArgs a)
+{
+    extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
+    __shared__ uint32_t s_ndrive, s_nstay;
+    __shared__ uint32_t gb[kGroups];
+    __shared__ uint32_t stage[GROUPED ? kGroups * kStage : 1];
+    const int Z = a.Z;
+    const int z = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t cap = a.cap;
+    const uint32_t b = static_cast<uint32_t>(z) * cap;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    // Scalar loads first, then the id loads -- written in assembly and waited for by hand: with LDS-DMA in flight hipcc
+    // (ROCm 7.2) drains vmcnt to 0 at the first use of any ordinary vector load result, which would put Philox behind the whole
+    // pack.  The wave issues CPT + 1 id loads, then exactly NQ LDS-DMA instructions; vmcnt retires in order, so vmcnt <= NQ
+    // means the ids are in their registers.
+    const uint32_t n_raw = a.cnt[z];
+    const double last = a.last_t[z];
+    const long long thr = a.thr_t[z];
+    uint32_t id[CPT + 1];
+#pragma unroll
+    for (int c = 0; c <= CPT; ++c) {
+        const uint32_t *src = a.ids + b + min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(id[c]) : "v"(src) : "memory");
+    }
+    pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
+    wait_ids<CPT + 1, NQ>(id);
+    const uint32_t n = min(n_raw, cap);
+    if (tid == 0) {
+        a.parking_t[z] = n;  // every car present at hour t, drivers included (src/saveresults.jl:12)
+        s_ndrive = 0;
+        s_nstay = 0;
+    }
+    if (tid < kGroups) gb[tid] = 0;
+    if (n == 0) {  // driving_t[z] stays 0 (zeroed by the caller)
+        if (GROUPED) {
+            if (tid == 0) a.cnt_next[z] = 0;
+            if (tid < kGroups) a.cntg[static_cast<size_t>(z) * kGroups + tid] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pack must not land in the LDS of the next workgroup
+        return;
+    }
+    // Philox of the register-resident cars: needs the ids only
+    bool valid[CPT], drive[CPT], want[CPT], ok[CPT];
+    uint32_t dest[CPT], clo[CPT], khi[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
+        long long kb;
+        car_draw_words(a.seed, a.cars.global(id[c]), a.step, kb, clo[c], khi[c]);
+        drive[c] = valid[c] & (kb <= thr);       // u <= p_drive[origin,t] (src/resampling.jl:15) in integers
+        want[c] = drive[c] & (last != 0.0);      // stays, or zero row: destination = origin (:35-36)
+    }
+    // This wave's pieces of the pack have landed (LDS-DMA counts in vmcnt; s_barrier itself waits for no counter), then the
+    // barrier makes every wave's pieces visible to every wave.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
+    const uint32_t hi_last = hi[Z - 1];
+    const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t nd = 0;
+    uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
+    uint32_t *runs = GROUPED ? a.D + static_cast<size_t>(z) * kGroups * a.scap : nullptr;
+    pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+    {
+        bool anyx = false;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
+            anyx |= want[c] & !ok[c];
+        }
+        if (__builtin_expect(__any(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
+        }
+    }
+    if (GROUPED) {
+        // stayers: one ticket per wave for all its CPT slots
+        unsigned long long mS[CPT];
+        uint32_t total = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            mS[c] = __ballot(valid[c] & !drive[c]);
+            total += static_cast<uint32_t>(__popcll(mS[c]));
+        }
+        uint32_t bS = 0;
+        if (lane == 0 && total) bS = atomicAdd(&s_nstay, total);
+        bS = __shfl(bS, 0, 64);
+        // drivers: CPT rank atomics in flight together
+        uint32_t rank[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (valid[c] & !drive[c]) stay_out[bS + static_cast<uint32_t>(__popcll(mS[c] & below))] = id[c];
+            bS += static_cast<uint32_t>(__popcll(mS[c]));
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (drive[c]) {
+                const uint32_t g = dest[c] >> a.gshift;
+                const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                if (rank[c] < static_cast<uint32_t>(kStage)) stage[g * kStage + rank[c]] = packed;
+                else if (rank[c] < a.scap) runs[g * a.scap + rank[c]] = packed;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (valid[c]) stay_out[tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
+            nd += drive[c] ? 1u : 0u;
+        }
+    }
+    for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
+        if (q0 + static_cast<uint32_t>(tid & ~63) >= n) continue;  // none of this wave's 64 slots holds a car (no barrier inside the loop)
+        const uint32_t q = q0 + tid;
+        const bool valid1 = q < n;
+        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q] : 0u);
+        const uint64_t car = a.cars.global(idx);
+        long long kb;
+        uint32_t clo1[1], khi1[1], dest1[1];
+        bool ok1[1], want1[1];
+        car_draw_words(a.seed, car, a.step, kb, clo1[0], khi1[0]);
+        const bool drive1 = valid1 & (kb <= thr);
+        want1[0] = drive1 & (last != 0.0);
+        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
+        if (!want1[0]) dest1[0] = z;
+        else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
+        if (GROUPED) {
+            const unsigned long long m1 = __ballot(valid1 & !drive1);
+            uint32_t b1 = 0;
+            if (lane == 0 && m1) b1 = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(m1)));
+            b1 = __shfl(b1, 0, 64);
+            if (valid1 & !drive1) stay_out[b1 + static_cast<uint32_t>(__popcll(m1 & below))] = idx;
+            if (drive1) {
+                const uint32_t g = dest1[0] >> a.gshift;
+                const uint32_t rank = atomicAdd(&gb[g], 1u);
+                const uint32_t packed = idx | ((dest1[0] & ((1u << a.gshift) - 1u)) << a.idbits);
+                if (rank < static_cast<uint32_t>(kStage)) stage[g * kStage + rank] = packed;
+                else if (rank < a.scap) runs[g * a.scap + rank] = packed;
+            }
+        } else {
+            if (valid1) stay_out[q] = dest1[0] | (drive1 ? kDriveBit : 0u);
+            nd += drive1 ? 1u : 0u;
+        }
+    }
+    if (!GROUPED) {
+        for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+        if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
+    }
+    __syncthreads();  // ranks, staged drivers and counters are final
+    if (GROUPED) {
+        // staged drivers -> their runs: 16 lanes per group, 64 B per store
+        for (int g = tid >> 4; g < kGroups; g += BLOCK / 16) {
+            const uint32_t lim = min(gb[g], static_cast<uint32_t>(kStage));
+            for (uint32_t i = tid & 15; i < lim; i += 16) runs[g * a.scap + i] = stage[g * kStage + i];
+        }
+        if (tid < kGroups) {
+            const uint32_t c = gb[tid];
+            a.cntg[static_cast<size_t>(z) * kGroups + tid] = min(c, a.scap);
+            if (c > a.scap) atomicOr(a.status, 2ull);  // a run outgrew its slot: the caller grows the regions and repeats
+        }
+    }
+    if (tid == 0) {
+        a.driving_t[z] = GROUPED ? n - s_nstay : s_ndrive;  // every car of the bucket either stays or drives
+        if (GROUPED) a.cnt_next[z] = s_nstay;  // k_grouped_place adds the arrivals
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ placing the drivers
+// Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share blockIdx % 8 (one XCD,
+// one L2: all writes to a bucket merge there; speed only, never correctness).  Block (g, j) takes the group-g runs of the origin
+// zones [j*zps, (j+1)*zps): 16 lanes per run, KDEEP entries per lane.  Run lengths and run contents sit at addresses known up
+// front, so they are requested together.
+constexpr int kPlaceBlock = 1024;
+constexpr int kPlaceSeg = kPlaceBlock / 16;
+
+template <int KRUNS, int KDEEP>
+__global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
+                                                               int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
+                                                               uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
+                                                               unsigned long long *status)
+{
+    // bins: entries held in registers per destination zone, then this block's base inside the zone's bucket;
+    // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those
+    __shared__ uint32_t bins[kMaxZonesPerGroup], tbins[kMaxZonesPerGroup];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x % kGroups, j = blockIdx.x / kGroups;
+    const int zg0 = g * zpg;
+    const int nzl = max(0, min(zpg, Z - zg0));
+    const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
+    const int sub = tid >> 4, l16 = tid & 15;
+    const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    for (int k = tid; k < zpg; k += kPlaceBlock) {
+        bins[k] = 0;
+        tbins[k] = 0;
+    }
+    if (zs0 >= zs1) return;  // (uniform per block)
+    uint32_t c[KRUNS], v[KRUNS][KDEEP], r[KRUNS][KDEEP];
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+        const int zs = zs0 + sub + k * kPlaceSeg;
+        const int zc = min(zs, zs1 - 1);
+        const size_t run = static_cast<size_t>(zc) * kGroups + g;
+        c[k] = cntg[run];
+        if (zs >= zs1) c[k] = 0;
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
+    }
+    __syncthreads();
+    // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d) {
+            r[k][d] = 0;
+            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        const size_t run = static_cast<size_t>(zc) * kGroups + g;
+        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) atomicAdd(&tbins[D[run * scap + i] >> idbits], 1u);
+    }
+    __syncthreads();
+    if (tid < nzl) {  // ticket: this block's range inside each bucket of the group
+        const uint32_t cr = bins[tid], ct = tbins[tid];
+        uint32_t base = 0;
+        if (cr + ct) {
+            base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
+            if (base + cr + ct > cap) atomicOr(status, 2ull);
+        }
+        bins[tid] = base;
+        tbins[tid] = base + cr;
+    }
+    __syncthreads();
+    // pass B: the ids move
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+#pragma unroll
+        for (int d = 0; d < KDEEP; ++d)
+            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) {
+                const uint32_t dl = v[k][d] >> idbits;
+                const uint32_t p = bins[dl] + r[k][d];
+                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = v[k][d] & idmask;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        const size_t run = static_cast<size_t>(zc) * kGroups + g;
+        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) {
+            const uint32_t w = D[run * scap + i];
+            const uint32_t dl = w >> idbits;
+            const uint32_t p = atomicAdd(&tbins[dl], 1u);
+            if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
+        }
+    }
+}
+
+// Blocks of the place kernel per destination group: at most 256 origin zones per block (one run per 16 lanes, four runs per
+// thread) from 1024 zones on -- measured at S4k: 8 blocks 16.9 us, 16 blocks 15.3 us.
+inline int place_bpg(int Z)
+{
+    if (Z < 1024) return 8;
+    int b = 16;
+    while (b < 64 && (Z + b - 1) / b > 256) b *= 2;
+    return b;
+}
+
+inline void grouped_launch_place(hipStream_t stream, const uint32_t *D, const uint32_t *cntg, int zpg, int Z, uint32_t cap, uint32_t scap,
+                                 uint32_t idbits, uint32_t *cnt_next, uint32_t *ids_next, unsigned long long *status)
+{
+    const int bpg = place_bpg(Z);
+    const int zps = (Z + bpg - 1) / bpg;
+    const dim3 grid(kGroups * bpg), block(kPlaceBlock);
+    if (zps <= 4 * kPlaceSeg)
+        hipLaunchKernelGGL((k_grouped_place<4, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
+    else
+        hipLaunchKernelGGL((k_grouped_place<8, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
+}
+
+// ------------------------------------------------------------------------------------------------ travel times
+// Travel times of an hour's drivers (src/resampling.jl:53-69), read back from the runs by a kernel of their own (inside the
+// sampler they cost it its occupancy: 138 VGPRs).  The sum is an integer in 2^-16 s units: order-free, bit-exact.
+constexpr int kTravelParts = 256;
+
+struct TravelArgs {
+    const double *dm;
+    unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
+    int T, t, gshift;
+    uint32_t step;
+    CarIndex cars;
+    uint64_t seed;
+};
+
+// one 256-thread block per origin zone
+__global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
+                                                        uint32_t idbits, TravelArgs tr)
+{
+    // The zone's drivers are dealt evenly over the threads whatever the run lengths are (popular destination groups
+    // hold most of them): driver i of the zone sits in run g with prefix[g] <= i < prefix[g+1].
+    __shared__ uint32_t prefix[kGroups + 1];
+    __shared__ unsigned long long s_tt;
+    const int z = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        const uint32_t c = (lane < kGroups) ? min(cntg[static_cast<size_t>(z) * kGroups + lane], scap) : 0u;
+        uint32_t incl = c;
+        for (int o = 1; o < kGroups; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane < kGroups) prefix[lane + 1] = incl;
+        if (lane == 0) {
+            prefix[0] = 0;
+            s_tt = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = prefix[kGroups];
+    const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    long long tt = 0;
+    // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
+    // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
+    constexpr int kTravelBatch = 4;
+    const size_t sd_off = static_cast<size_t>(Z) * Z * tr.T;
+    for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
+        uint32_t w[kTravelBatch], dest[kTravelBatch];
+        bool live[kTravelBatch];
+#pragma unroll
+        for (int u = 0; u < kTravelBatch; ++u) {
+            const uint32_t i = i0 + u * blockDim.x;
+            live[u] = i < total;
+            uint32_t g = 0;
+#pragma unroll
+            for (int step = kGroups / 2; step > 0; step >>= 1)
+                if (prefix[g + step] <= i) g += step;
+            g = live[u] ? g : 0u;
+            w[u] = live[u] ? D[(static_cast<size_t>(z) * kGroups + g) * scap + (i - prefix[g])] : 0u;
+            dest[u] = (g << tr.gshift) + (w[u] >> idbits);
+        }
+        double mean[kTravelBatch], sd[kTravelBatch];
+#pragma unroll
+        for (int u = 0; u < kTravelBatch; ++u) {
+            const bool moving = live[u] && dest[u] != static_cast<uint32_t>(z);
+            const size_t cell = static_cast<size_t>(z) + static_cast<size_t>(Z) * (dest[u] + static_cast<size_t>(Z) * tr.t);
+            mean[u] = moving ? tr.dm[cell] : 0.0;
+            sd[u] = moving ? tr.dm[cell + sd_off] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kTravelBatch; ++u) {
+            if (!live[u]) continue;
+            if (dest[u] == static_cast<uint32_t>(z)) {  // same zone: 300 s (src/resampling.jl:58-60)
+                tt += q16(300.0);
+            } else {
+                const double s1 = (sd[u] == 0) ? 0.1 * mean[u] : sd[u];  // :65-67
+                tt += q16(truncnormal_pm10(tr.seed, tr.cars.global(w[u] & idmask), tr.step, 1, mean[u], s1));
+            }
+        }
+    }
+    // one global atomic per block, spread over kTravelParts words (atomics on ONE word are served one at a time at the memory
+    // side: four per block on the sum itself made this kernel 119 us per hour); k_grouped_travel_finish adds the parts up
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
+    if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
+    __syncthreads();
+    if (tid == 0 && s_tt) atomicAdd(&tr.tt_part[z % kTravelParts], s_tt);
+}
+
+__global__ __launch_bounds__(256) void k_grouped_travel_finish(unsigned long long *__restrict__ tt_part, unsigned long long *__restrict__ tt_sum)
+{
+    unsigned long long v = tt_part[threadIdx.x];
+    tt_part[threadIdx.x] = 0;  // ready for the next resample
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(tt_sum, v);
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+constexpr int kSampleBlock = 256;  // measured at S4k: 512 threads x 2 cars: 31 us, 256 x 4: 28, 128 x 8: 44
+
+template <bool GROUPED, int CPT, int NQ>
+inline void grouped_launch_nq(const GroupedArgs &a, size_t lds, hipStream_t stream)
+{
+    if (lds > 48 * 1024) {  // LDS opt-in, once per device (contexts of several devices may live in one process)
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>), dim3(a.Z), dim3(kSampleBlock), lds, stream, a);
+}
+
+template <bool GROUPED, int CPT>
+inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
+{
+    const int words = pack_row_words(a.Zq, a.G);
+    const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
+    const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (need <= 1) grouped_launch_nq<GROUPED, CPT, 1>(a, lds, stream);
+    else if (need <= 2) grouped_launch_nq<GROUPED, CPT, 2>(a, lds, stream);
+    else if (need <= 3) grouped_launch_nq<GROUPED, CPT, 3>(a, lds, stream);
+    else if (need <= 4) grouped_launch_nq<GROUPED, CPT, 4>(a, lds, stream);
+    else if (need <= 5) grouped_launch_nq<GROUPED, CPT, 5>(a, lds, stream);
+    else if (need <= 6) grouped_launch_nq<GROUPED, CPT, 6>(a, lds, stream);
+    else if (need <= 8) grouped_launch_nq<GROUPED, CPT, 8>(a, lds, stream);
+    else if (need <= 12) grouped_launch_nq<GROUPED, CPT, 12>(a, lds, stream);
+    else if (need <= 20) grouped_launch_nq<GROUPED, CPT, 20>(a, lds, stream);
+    else grouped_launch_nq<GROUPED, CPT, 40>(a, lds, stream);
+}
+
+// Cars per thread by the mean bucket size (cars of this GPU / zones): 256 x 4 slots for ~1000 cars per zone, 256 x 2 and 256 x 1
+// for smaller buckets (every slot runs Philox whether a car sits in it or not); larger buckets take the overflow rounds.
+template <bool GROUPED>
+inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+{
+    if (mean <= 224) grouped_launch_c<GROUPED, 1>(a, stream);
+    else if (mean <= 560) grouped_launch_c<GROUPED, 2>(a, stream);
+    else grouped_launch_c<GROUPED, 4>(a, stream);
+}
+
+// Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
+// installed row, through the same staging, search and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
+__global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__restrict__ pack_g, const double *__restrict__ last_p,
+                                                           const double *__restrict__ cdf_row, int Z, int Zq, int G, int64_t n,
+                                                           const uint64_t *__restrict__ k53, int64_t *__restrict__ out, int *__restrict__ n_exact)
+{
+    extern __shared__ uint32_t pack[];
+    const int tid = threadIdx.x;
+    const int gw = pack_guide_words(G), pieces = pack_row_words(Zq, G) / 4, sh = 32 - G;
+    {
+        const int lane = tid & 63;
+        for (int p0 = tid - lane; p0 < pieces; p0 += 512) {  // wave-uniform trips
+            const int p = p0 + lane;
+            if (p < pieces)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(pack_g) + p,
+                                                 (__attribute__((address_space(3))) void *)(pack + 4 * p0), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
+    const double last = *last_p;
+    const uint32_t hi_last = hi[Z - 1];
+    for (int64_t i0 = 0; i0 < n; i0 += 512) {  // wave-uniform trips (pack_search votes across the wave)
+        const int64_t i = i0 + tid;
+        const bool live = i < n;
+        const uint64_t k = live ? k53[i] & ((1ull << 53) - 1ull) : 0ull;
+        uint32_t dest[1];
+        bool ok[1];
+        const uint32_t khi[1] = {static_cast<uint32_t>(k >> 21)};
+        const bool want[1] = {live && last != 0.0};
+        pack_search<1>(guide, hi, khi, want, sh, hi_last, Zq, dest, ok);
+        if (!live) continue;
+        if (last == 0.0) {
+            out[i] = 0;
+            continue;
+        }
+        if (!ok[0]) {
+            dest[0] = search_exact_row(cdf_row, Z, static_cast<double>(k) * 0x1.0p-53, last);
+            atomicAdd(n_exact, 1);
+        }
+        out[i] = static_cast<int64_t>(dest[0]) + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ workspace and driver
+// run capacity: a quarter of a bucket region (= the mean bucket size at cap_mult 4), >= 64, whole 128-B lines
+inline uint32_t grouped_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
+// groups of 2^gshift consecutive zones, at most kGroups of them
+inline uint32_t grouped_gshift(int Z)
+{
+    uint32_t s = 0;
+    while ((static_cast<int64_t>(kGroups) << s) < Z) ++s;
+    return s;
+}
+// packed driver = id | (dest mod 2^gshift) << idbits
+inline uint32_t grouped_idbits(int Z) { return 32u - std::max(1u, grouped_gshift(Z)); }
+inline uint32_t grouped_cap(int64_t n, int Z, int cap_mult)
+{
+    const int64_t mean = (n + Z - 1) / Z;
+    return static_cast<uint32_t>((std::max<int64_t>(cap_mult * mean, 1024) + 63) / 64 * 64);
+}
+
+// true when the path can run this problem: the row pack fits LDS, ids fit the packed driver word, the bucket and run arrays fit
+// their budget (3 id arrays of Z x cap x 4 B and Z x 32 x scap x 4 B of runs: <= 24 GiB, 80 GiB once grown)
+inline bool grouped_path_fits(int64_t n, int Z, int cap_mult = 4)
+{
+    if (!pack_row_fits(Z) || n < 1 || n >= (int64_t(1) << 30)) return false;
+    const uint32_t cap = grouped_cap(n, Z, cap_mult);
+    if (n > (int64_t(1) << grouped_idbits(Z)) || (1 << grouped_gshift(Z)) > kMaxZonesPerGroup) return false;
+    if ((Z + place_bpg(Z) - 1) / place_bpg(Z) > 8 * kPlaceSeg) return false;
+    const int64_t bytes = static_cast<int64_t>(Z) * cap * 4 * 3 + static_cast<int64_t>(Z) * kGroups * grouped_scap(cap) * 4;
+    return bytes <= (int64_t(cap_mult <= 4 ? 24 : 80) << 30);
+}
+
+struct GroupedWork {
+    bool attrs_set = false;
+    bool buckets0_valid = false;  // ids0 / cnt0 describe the context's current car state
+    int64_t n = 0;
+    int Z = 0, T = 0, nb0 = 0;
+    int cap_mult = 4;        // bucket region = cap_mult x the mean bucket size; doubled by the context after an overflow (up to kMaxCapMult)
+    int cap_mult_alloc = 0;  // what the arrays below were sized for
+    uint32_t cap = 0, scap = 0, idbits = 0, gshift = 0;
+    uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [Z*cap]: cached initial bucketing, ping-pong
+    uint32_t *cnt0 = nullptr;                                    // [Z] sizes of the cached initial buckets
+    uint32_t *cnt = nullptr;                                     // [T+1][Z] bucket sizes per hour
+    uint32_t *Dq = nullptr;                                      // [Z][kGroups][scap] packed drivers
+    uint32_t *cntg = nullptr;                                    // [Z][kGroups] run lengths
+    unsigned long long *tt_part = nullptr;                       // [kTravelParts] partial travel-time sums, kept zero between resamples
+    const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
+
+    void release()
+    {
+        for (uint32_t **p : {&ids0, &idsA, &idsB, &cnt0, &cnt, &Dq, &cntg}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        if (tt_part) (void)hipFree(tt_part);
+        tt_part = nullptr;
+        n = 0;
+        buckets0_valid = false;
+    }
+
+    hipError_t ensure(int64_t n_, int Z_, int T_, int cu_count)
+    {
+        if (n_ == n && Z_ == Z && T_ == T && ids0 && cap_mult_alloc == cap_mult) return hipSuccess;
+        release();
+        n = n_;
+        Z = Z_;
+        T = T_;
+        cap_mult_alloc = cap_mult;
+        cap = grouped_cap(n, Z, cap_mult);
+        scap = grouped_scap(cap);
+        idbits = grouped_idbits(Z);
+        gshift = grouped_gshift(Z);
+        nb0 = static_cast<int>(std::max<int64_t>({int64_t(1), std::min<int64_t>(2 * cu_count, (n + 4095) / 4096),
+                                                  (n + int64_t(kBucketMaxPass) * 1024 - 1) / (int64_t(kBucketMaxPass) * 1024)}));
+        hipError_t e = hipSuccess;
+        auto alloc = [&](uint32_t **p, size_t words) {
+            if (e == hipSuccess) e = hipMalloc(p, sizeof(uint32_t) * std::max<size_t>(words, 1));
+        };
+        const size_t slots = static_cast<size_t>(Z) * cap;
+        alloc(&ids0, slots);
+        alloc(&idsA, slots);
+        alloc(&idsB, slots);
+        alloc(&cnt0, Z);
+        alloc(&cnt, static_cast<size_t>(T + 1) * Z);
+        alloc(&Dq, static_cast<size_t>(Z) * kGroups * scap);
+        alloc(&cntg, static_cast<size_t>(Z) * kGroups);
+        if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
+        if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
+        if (e != hipSuccess) release();
+        return e;
+    }
+};
+
+struct GroupedTables {
+    const uint32_t *rp;      // [T][Z][RW]
+    const double *last;      // [T][Z]
+    const long long *thr;    // [T][Z]
+    const double *cdf;       // [T][Z][Zp]
+    const double *dm;        // datamatrix (travel times) or nullptr
+    int Z, Zp, Zq, T;
+};
+
+// ivp == false: the T-hour resample from the state in d_zone0 (left unchanged).  On overflow bit 1 of the status word
+//               (d_counts[2*T*Z+1]) is set and the counts are invalid.
+// ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps 0..T-2, every transition
+//               applied.  d_zone0 is NOT modified: the new car-indexed state goes to d_zone0_out and the final buckets are
+//               remembered in w.ivp_ids / w.ivp_cnt.  The caller inspects the status word when the stream has drained and then
+//               either commits (grouped_commit_ivp + pointer swap) or repeats the IVP from the untouched d_zone0.
+template <typename F1, typename F2>
+int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb, int64_t n, CarIndex cars, const uint32_t *d_zone0,
+                    uint64_t seed, bool travel, int64_t *d_counts, int cu_count, F1 prof_begin, F2 prof_end, std::string &err, bool ivp = false,
+                    uint32_t *d_zone0_out = nullptr)
+{
+    auto hip_fail = [&](hipError_t e, const char *what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? CPM_ERR_NOMEM : CPM_ERR_HIP;
+    };
+    const int Z = tb.Z, T = tb.T;
+    hipError_t e = w.ensure(n, Z, T, cu_count);
+    if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
+    const size_t lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
+    if (!w.attrs_set) {
+        if (lds_bins > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bucket_cars), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bins));
+        w.attrs_set = true;
+    }
+    unsigned long long *parking = reinterpret_cast<unsigned long long *>(d_counts);
+    unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
+    unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
+    unsigned long long *status = tt_sum + 1;
+    e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
+    if (e != hipSuccess) return hip_fail(e, "memset counters");
+    if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
+        const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
+        if ((e = hipMemsetAsync(w.cnt0, 0, sizeof(uint32_t) * Z, stream)) != hipSuccess) return hip_fail(e, "memset cnt0");
+        hipLaunchKernelGGL(k_bucket_cars, dim3(w.nb0), dim3(kBucketBlock), lds_bins, stream, d_zone0, n, chunk, Z, w.cap, w.cnt0, w.ids0, status);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
+        w.buckets0_valid = true;
+    }
+    const int G = pack_guide_bits(Z);
+    const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G));
+    const int64_t mean = (n + Z - 1) / Z;
+    const uint32_t *ids = w.ids0, *cnt = w.cnt0;
+    const int hours = ivp ? T - 1 : T;
+    for (int t = 0; t < hours; ++t) {
+        const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
+        // hour T of a resample is sampled, never applied (src/resampling.jl:81-83): counts only -- unless its travel times are wanted,
+        // which are computed from the runs
+        const bool last_hour = !ivp && t + 1 == T;
+        const bool grouped = !last_hour || travel;
+        uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * Z;
+        uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
+        GroupedArgs a;
+        a.ids = ids;
+        a.cnt = cnt;
+        a.rp_t = tb.rp + static_cast<size_t>(t) * Z * rw;
+        a.last_t = tb.last + static_cast<size_t>(t) * Z;
+        a.thr_t = tb.thr + static_cast<size_t>(t) * Z;
+        a.cdf_t = tb.cdf + static_cast<size_t>(t) * Z * tb.Zp;
+        a.ids_next = ids_next;
+        a.cnt_next = cnt_next;
+        a.D = w.Dq;
+        a.cntg = w.cntg;
+        a.parking_t = parking + static_cast<size_t>(t) * Z;
+        a.driving_t = driving + static_cast<size_t>(t) * Z;
+        a.status = status;
+        a.Z = Z;
+        a.Zp = tb.Zp;
+        a.Zq = tb.Zq;
+        a.G = G;
+        a.cap = w.cap;
+        a.scap = w.scap;
+        a.idbits = w.idbits;
+        a.gshift = w.gshift;
+        a.step = step;
+        a.cars = cars;
+        a.seed = seed;
+        prof_begin(t);
+        if (grouped) grouped_launch_sample<true>(a, mean, stream);
+        else grouped_launch_sample<false>(a, mean, stream);
+        prof_end(t);
+        if (!last_hour) {
+            grouped_launch_place(stream, w.Dq, w.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next, ids_next, status);
+            ids = ids_next;
+            cnt = cnt_next;
+        }
+        if (travel && grouped) {
+            TravelArgs tr{};
+            tr.dm = tb.dm;
+            tr.tt_part = w.tt_part;
+            tr.T = T;
+            tr.t = t;
+            tr.gshift = static_cast<int>(w.gshift);
+            tr.step = step;
+            tr.cars = cars;
+            tr.seed = seed;
+            hipLaunchKernelGGL(k_grouped_travel, dim3(Z), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
+    }
+    if (travel && !ivp) {  // the partial sums of k_grouped_travel -> the sum word of the count tensor
+        hipLaunchKernelGGL(k_grouped_travel_finish, dim3(1), dim3(kTravelParts), 0, stream, w.tt_part, tt_sum);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "travel-time sum");
+    }
+    if (ivp) {
+        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, w.cap, d_zone0_out);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
+        w.ivp_ids = ids;
+        w.ivp_cnt = cnt;
+        w.buckets0_valid = false;  // until grouped_commit_ivp
+    }
+    return CPM_OK;
+}
+
+// After a verified IVP: its final buckets become the cached bucketing of the (new) current state.
+inline hipError_t grouped_commit_ivp(GroupedWork &w, hipStream_t stream)
+{
+    hipError_t e = hipSuccess;
+    if (w.ivp_ids != w.ids0) e = hipMemcpyAsync(w.ids0, w.ivp_ids, sizeof(uint32_t) * static_cast<size_t>(w.Z) * w.cap, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.cnt0, w.ivp_cnt, sizeof(uint32_t) * w.Z, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) w.buckets0_valid = true;
+    return e;
+}
+
+}  // namespace cpm

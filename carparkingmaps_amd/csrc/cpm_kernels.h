@@ -21,13 +21,25 @@ constexpr uint32_t kDriveBit = 0x80000000u;
 constexpr uint32_t kZoneMask = 0x7fffffffu;
 constexpr double kTrueMin = 4.9406564584124654e-324;
 
+// The cars a context simulates: local car i (0-based index into the context's state) is the GLOBAL car begin + i * stride of
+// the whole fleet.  stride 1 = a contiguous shard; stride N = the interleaved deal over N GPUs (car g belongs to rank g mod N).
+// Philox is keyed by the global id, so a car's draws do not depend on how the fleet is dealt.
+struct CarIndex {
+    int64_t begin;
+    uint32_t stride;
+    __host__ __device__ __forceinline__ uint64_t global(uint32_t local) const
+    {
+        return static_cast<uint64_t>(begin) + static_cast<uint64_t>(local) * stride;  // one v_mad_u64_u32
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // initializestates (src/initializestates.jl:11-16): global car g starts in zone g / cpz.
 // ---------------------------------------------------------------------------------------
-__global__ void k_init_states(uint32_t *zone0, int64_t car_begin, int64_t n, int64_t cpz)
+__global__ void k_init_states(uint32_t *zone0, CarIndex cars, int64_t n, int64_t cpz)
 {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) zone0[i] = static_cast<uint32_t>((car_begin + i) / cpz);
+    if (i < n) zone0[i] = static_cast<uint32_t>(cars.global(static_cast<uint32_t>(i)) / static_cast<uint64_t>(cpz));
 }
 
 __global__ void k_zones_from_i64(uint32_t *zone0, const int64_t *zones1, int64_t n, int64_t Z, int *err)
@@ -225,7 +237,7 @@ template <bool TRAVEL>
 __global__ __launch_bounds__(256) void k_step_car(const uint32_t *__restrict__ zin, uint32_t *__restrict__ rec_out,
                                                   const double *__restrict__ pdrive_t,
                                                   const double *__restrict__ cdf_t, int Z, int Zp, int64_t n,
-                                                  int64_t car_begin, uint32_t step, uint64_t seed,
+                                                  CarIndex cars, uint32_t step, uint64_t seed,
                                                   const double *__restrict__ dm, int T, int t,
                                                   unsigned long long *tt_sum)
 {
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256) void k_step_car(const uint32_t *__restrict__ z
     long long tt = 0;
     if (i < n) {
         uint32_t zone = zin[i] & kZoneMask;
-        uint64_t car = static_cast<uint64_t>(car_begin + i);
+        uint64_t car = cars.global(static_cast<uint32_t>(i));
         double ub, uc;
         car_uniforms(seed, car, step, 0, ub, uc);
         bool drive = ub <= pdrive_t[zone];
@@ -306,7 +318,7 @@ __global__ void k_histogram_global(const uint32_t *__restrict__ zone0, const uin
 // re-derived from the same Philox streams, so nothing extra is stored per car.
 // ---------------------------------------------------------------------------------------
 __global__ void k_export_hour(const uint32_t *__restrict__ zsrc, const uint32_t *__restrict__ rec_t, int64_t n,
-                              int64_t car_begin, int64_t *__restrict__ state_col, double *__restrict__ drive_col,
+                              CarIndex cars, int64_t *__restrict__ state_col, double *__restrict__ drive_col,
                               double *__restrict__ dest_col, double *__restrict__ time_col,
                               double *__restrict__ dist_col, const double *__restrict__ dm,
                               const double *__restrict__ dist, int Z, int T, int t, uint32_t step, uint64_t seed)
@@ -326,7 +338,7 @@ __global__ void k_export_hour(const uint32_t *__restrict__ zsrc, const uint32_t 
             tm = 300.0;
             ds = 1.0;
         } else {
-            uint64_t car = static_cast<uint64_t>(car_begin + i);
+            uint64_t car = cars.global(static_cast<uint32_t>(i));
             size_t cell = zone + static_cast<size_t>(Z) * (dest + static_cast<size_t>(Z) * t);
             double mean = dm[cell];
             double sd = dm[cell + static_cast<size_t>(Z) * Z * T];

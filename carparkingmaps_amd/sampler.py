@@ -30,6 +30,7 @@ class Sampler:
         _lib.check(self._L.cpm_create(C.byref(h), self.Z, self.T, self.device))
         self._h = h
         self.C_total = self.cars_per_zone = self.car_begin = self.car_count = 0
+        self.car_stride = 1
 
     # -- lifetime ----------------------------------------------------------
     def close(self):
@@ -52,10 +53,6 @@ class Sampler:
     # -- options -----------------------------------------------------------
     def set_kernel(self, kernel):
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
-
-    def set_option(self, option, value):
-        """Raw cpm_set_option (tuning / A-B options of include/cpm.h)."""
-        _lib.check(self._L.cpm_set_option(self._h, int(option), int(value)))
 
     def get_info(self, what):
         """cpm_get_info: 1 = kernel family AUTO resolves to now, 2 = bucket-region size in multiples of the mean bucket."""
@@ -147,11 +144,15 @@ class Sampler:
         return out
 
     # -- cars --------------------------------------------------------------
-    def init_states(self, C_total, cars_per_zone, car_begin=0, car_count=None):
-        car_count = int(C_total) - int(car_begin) if car_count is None else int(car_count)
-        _lib.check(self._L.cpm_init_states(self._h, int(C_total), int(cars_per_zone), int(car_begin), car_count))
+    def init_states(self, C_total, cars_per_zone, car_begin=0, car_count=None, car_stride=1):
+        """This context simulates the global cars car_begin + k * car_stride, k < car_count (stride 1: a contiguous range)."""
+        car_stride = int(car_stride)
+        if car_count is None:
+            car_count = max(0, -(-(int(C_total) - int(car_begin)) // car_stride))
+        car_count = int(car_count)
+        _lib.check(self._L.cpm_init_states_strided(self._h, int(C_total), int(cars_per_zone), int(car_begin), car_stride, car_count))
         self.C_total, self.cars_per_zone = int(C_total), int(cars_per_zone)
-        self.car_begin, self.car_count = int(car_begin), car_count
+        self.car_begin, self.car_count, self.car_stride = int(car_begin), car_count, car_stride
 
     def set_state(self, zones):
         z = np.ascontiguousarray(zones, dtype=np.int64)

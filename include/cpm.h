@@ -56,22 +56,17 @@ extern "C" {
 /* cpm_resample flags */
 #define CPM_FLAG_TRAVEL 1u      /* pass 3 of src/resampling.jl:53-78 (needs cpm_set_datamatrix) */
 
-/* search kernels (cpm_set_option CPM_OPT_KERNEL) */
+/* kernel families (cpm_set_option CPM_OPT_KERNEL) */
 #define CPM_KERNEL_AUTO 0
-#define CPM_KERNEL_CAR 1        /* one thread per car, CDF searched in HBM/L2 */
-#define CPM_KERNEL_ZONE_LDS 2   /* cars bucketed by zone, CDF row staged in LDS; exact (packed) bucket layout, three launches per hour */
-/* 3 was an experimental persistent-workgroup form, removed (profiles/round1_notes.md) */
+#define CPM_KERNEL_CAR 1          /* one thread per car, CDF searched in HBM/L2; also what fills the reference's full state_matrix / transition_matrix */
+#define CPM_KERNEL_ZONE_LDS 2     /* cars bucketed by zone, f64 CDF row staged in LDS; exact (packed) bucket layout, three launches per hour;
+                                   * cannot overflow: the fallback of the grouped path */
 #define CPM_KERNEL_ZONE_GROUPED 5 /* what AUTO runs: fixed-stride buckets, row packs (guide + 4-byte CDF high words, exact f64 fallback on ties)
                                    * staged by LDS-DMA, stayers kept by the sampler, drivers placed per destination group; two launches per hour */
-#define CPM_KERNEL_ZONE_STRIDED 4 /* zone path with fixed-stride buckets: the counting sort is one kernel per hour */
 
 #define CPM_OPT_KERNEL 1
 #define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
                                    pair costs ~10 us of stream bubbles, so sample); 0: off */
-#define CPM_OPT_ZONE_BLOCK 3    /* A/B, exact layout only: 0 = tree-layout sampler (default); 256 / 512 = first-generation sorted-row sampler */
-#define CPM_OPT_PLACE_SHAPE 4   /* tuning: grouped path, blocks per destination group * 10 + entries per lane (82, 81, 162, 161); 0 = by zone count */
-#define CPM_OPT_GROUPED_GEN 5   /* A/B: 6 (default) = row packs + fixed-size runs, 5 = first generation of the grouped path (f64 rows, offsets) */
-#define CPM_OPT_ABLATE 100      /* diagnostic only: disables parts of the sampler, results WRONG */
 
 typedef struct cpm_ctx cpm_ctx;
 
@@ -149,6 +144,12 @@ int32_t cpm_get_cdf_row(cpm_ctx *ctx, int64_t origin1, int64_t hour1, double *cd
  * [car_begin, car_begin + car_count) of the C_total cars. */
 int32_t cpm_init_states(cpm_ctx *ctx, int64_t C_total, int64_t cars_per_zone, int64_t car_begin,
                         int64_t car_count);
+/* the same for the interleaved deal of a multi-GPU run: this context simulates the global cars
+ * car_first + k * car_stride, k = 0 .. car_count - 1 (rank r of N: car_first = r, car_stride = N).  Every rank then starts with
+ * its share of EVERY zone, instead of all cars of 1/N of the zones as with contiguous ranges; results are identical either
+ * way (Philox is keyed by the global car id). */
+int32_t cpm_init_states_strided(cpm_ctx *ctx, int64_t C_total, int64_t cars_per_zone, int64_t car_first,
+                                int64_t car_stride, int64_t car_count);
 /* state_matrix[:,1] = initial_state (main.jl:92): zones 1-based, car_count entries */
 int32_t cpm_set_state(cpm_ctx *ctx, const int64_t *zones);
 int32_t cpm_get_state(cpm_ctx *ctx, int64_t *zones_out);

@@ -527,7 +527,7 @@ static inline int64_t categorical_cdf(const double *row, int64_t Z, int64_t orig
 }
 
 int orc_fast_run(const double *p_drive, const double *cdf, int64_t Z, int64_t T, int64_t C,
-                 int64_t car_offset, uint64_t seed, int do_ivp, int64_t *zone0,
+                 int64_t car_offset, int64_t car_stride, uint64_t seed, int do_ivp, int64_t *zone0,
                  int64_t *parking, int64_t *driving, int64_t *state_out, const double *dm,
                  const double *dist, int64_t *sum_tt_q16, int nthreads)
 {
@@ -547,7 +547,7 @@ int orc_fast_run(const double *p_drive, const double *cdf, int64_t Z, int64_t T,
         int64_t *ld = lp + Z * T;
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < C; ++i) {
-            uint64_t car = (uint64_t)(car_offset + i);
+            uint64_t car = (uint64_t)(car_offset + i * car_stride);  /* global car id: contiguous shard (stride 1) or interleaved deal */
             int64_t zone = zone0[i];
             if (zone < 1 || zone > Z) { err = 1; continue; }
             int bad = 0;

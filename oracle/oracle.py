@@ -58,7 +58,7 @@ def lib():
     L.orc_correctparameters.argtypes = [dbl, dbl, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl)]
     L.orc_correctparameters.restype = None
     L.orc_build_cdf.argtypes = [_f64p, i64, i64, vp]
-    L.orc_fast_run.argtypes = [_f64p, vp, i64, i64, i64, i64, u64, C.c_int, _i64p, _i64p, _i64p,
+    L.orc_fast_run.argtypes = [_f64p, vp, i64, i64, i64, i64, i64, u64, C.c_int, _i64p, _i64p, _i64p,
                                vp, vp, vp, vp, C.c_int]
     L.orc_synth_p_drive.argtypes = [i64, i64, u64, _f64p]
     L.orc_synth_p_dest_dense.argtypes = [i64, i64, u64, _f64p]
@@ -177,7 +177,7 @@ def build_cdf(p_dest):
 
 
 def fast_run(p_drive, cdf, C_, seed, zone0, car_offset=0, do_ivp=True, want_state=False,
-             datamatrix=None, dist=None, nthreads=0):
+             datamatrix=None, dist=None, nthreads=0, car_stride=1):
     """IVP (optional) + resample; returns dict(parking, driving [Z x T int64 F-order],
     zone0 (post-IVP zones), state (C x T) or None, sum_tt_q16)."""
     Z, T = p_drive.shape
@@ -186,7 +186,7 @@ def fast_run(p_drive, cdf, C_, seed, zone0, car_offset=0, do_ivp=True, want_stat
     driving = np.zeros((Z, T), dtype=np.int64, order="F")
     state = np.zeros((C_, T), dtype=np.int64, order="F") if want_state else None
     tt = C.c_int64(0)
-    _check(lib().orc_fast_run(p_drive, _ptr(cdf), Z, T, C_, car_offset, seed, int(do_ivp), zone0, parking,
+    _check(lib().orc_fast_run(p_drive, _ptr(cdf), Z, T, C_, car_offset, car_stride, seed, int(do_ivp), zone0, parking,
                               driving, _ptr(state), _ptr(datamatrix), _ptr(dist),
                               C.cast(C.byref(tt), C.c_void_p), nthreads), "fast_run")
     return dict(parking=parking, driving=driving, zone0=zone0, state=state, sum_tt_q16=tt.value)

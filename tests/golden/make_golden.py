@@ -9,6 +9,7 @@ that do not depend on the oracle being rebuilt.
 
     python tests/golden/make_golden.py            # small vectors (seconds)
     python tests/golden/make_golden.py --big      # + checksums of the headline configs (minutes, ~8 GB)
+    python tests/golden/make_golden.py --s8k      # only: checksums of two ranks' shards of the 8-GPU configuration (~26 GB)
 """
 import hashlib
 import json
@@ -81,7 +82,40 @@ def big():
     json.dump(out, open(os.path.join(HERE, "big_checksums.json"), "w"), indent=1)
 
 
+def s8k_shards():
+    """BASELINE.json configs[3]: Z = 8,192, 4,000 cars/zone (C = 32,768,000) dealt over 8 GPUs.  Checksums of what ranks 0 and 7
+    compute (IVP + resample of their 4,096,000 cars), for the contiguous deal (shard_range) and for the interleaved one
+    (car g -> rank g mod 8).  ~26 GB of host memory, minutes on 8 cores."""
+    Z, cpz, world = 8192, 4000, 8
+    C = Z * cpz
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)
+    cdf = O.build_cdf(p_dest)
+    del p_dest
+    out = {"Z": Z, "cpz": cpz, "C": C, "world": world, "table_seed": TABLE_SEED, "sim_seed": SIM_SEED, "shards": {}}
+    n = C // world
+    for deal in ("contiguous", "interleaved"):
+        for rank in (0, world - 1):
+            if deal == "contiguous":
+                first, stride = rank * n, 1
+            else:
+                first, stride = rank, world
+            cars = first + stride * np.arange(n, dtype=np.int64)
+            r = O.fast_run(p_drive, cdf, n, SIM_SEED, cars // cpz + 1, car_offset=first, car_stride=stride)
+            out["shards"][f"{deal}_rank{rank}"] = {
+                "car_first": first, "car_stride": stride, "car_count": n,
+                "initial_state_sha256": sha(r["zone0"]), "parking_sha256": sha(r["parking"].ravel(order="F")),
+                "driving_sha256": sha(r["driving"].ravel(order="F")), "driving_total": int(r["driving"].sum()),
+                "parking_hour24_first8": [int(x) for x in r["parking"][:8, 23]],
+                "parking_max": int(r["parking"].max())}
+            print(deal, rank, out["shards"][f"{deal}_rank{rank}"], flush=True)
+    json.dump(out, open(os.path.join(HERE, "s8k_shard_checksums.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    if "--s8k" in sys.argv:
+        s8k_shards()
+        sys.exit(0)
     small()
     if "--big" in sys.argv:
         big()

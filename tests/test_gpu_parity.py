@@ -9,18 +9,11 @@ from conftest import SIM_SEED, TABLE_SEED
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"),
-           pytest.param(4, id="zone_strided"), pytest.param(5, id="zone_grouped"),
-           pytest.param(55, id="zone_grouped_gen5")]
+KERNELS = [pytest.param(0, id="auto"), pytest.param(1, id="car"), pytest.param(2, id="zone_lds"), pytest.param(5, id="zone_grouped")]
 
 
 def _set_kernel(s, kernel):
-    """55: the grouped path's first generation (f64 rows, per-zone offsets)."""
-    if kernel == 55:
-        s.set_kernel(5)
-        s.set_option(5, 5)
-    else:
-        s.set_kernel(kernel)
+    s.set_kernel(kernel)
 
 
 def _tables(O, Z, T=24, seed=TABLE_SEED):
@@ -323,7 +316,7 @@ def test_headline_config_full_size(cpm, O):
         assert np.array_equal(r["driving"], ref["driving"])
         assert (r["parking"].sum(axis=0) == C).all()
         np.testing.assert_allclose(r["parking"] / C, ref["parking"] / C, rtol=1e-6, atol=0)
-        for kernel in (1, 2, 4):  # the other kernels agree at full size too
+        for kernel in (1, 2):  # the other kernels agree at full size too
             _set_kernel(s, kernel)
             r2 = s.resample(SIM_SEED)
             assert np.array_equal(r2["parking"], ref["parking"]) and np.array_equal(r2["driving"], ref["driving"])
@@ -426,7 +419,7 @@ def test_fixed_stride_overflow_is_reported_and_auto_demotes_itself(cpm, O):
         s.set_p_dest(p_dest)
         s.init_states(C, cpz)
         counts = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
-        for kernel in (5, 4):
+        for kernel in (5,):
             _set_kernel(s, kernel)
             s.resample_dev(SIM_SEED, counts.data_ptr())
             s.sync()
