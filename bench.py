@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- car-steps/s of the 24-hour resample (src/resampling.jl + the saveresults
-histogram) on N MI355X, with the HBM roofline of the hourly sampler kernel and the CPU
-restatement timed beside it.
+histogram) on N MI355X, with the HBM roofline of the path and the CPU restatement timed beside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full T=24 hour resample of every car (tables, CDF and the post-IVP initial
 state already resident in HBM), through the zone x hour count tensor -- and, for N > 1, through
-the single RCCL all-reduce of that tensor.  Workload at N = 1: synthetic dense Z = 4,096 zones,
+the single RCCL all-reduce of that tensor (step k's all-reduce runs under step k+1's kernels; the
+timed region ends when the last one has finished).  Workload at N = 1: synthetic dense Z = 4,096 zones,
 1,000 cars/zone (BASELINE.json configs[2], the configuration the metric is quoted on).  For
-N > 1 the cars per GPU stay fixed (weak scaling): Z = 4,096, 1,000*N cars/zone sharded by car.
+N > 1 the cars per GPU stay fixed (weak scaling): Z = 4,096, 1,000*N cars/zone, car g on rank g mod N.
+
+roofline: B = algorithmic HBM bytes of one hourly launch = rows + Z*8 (p_drive) + C_g*8 (4 B id in, 4 B out)
++ 2*Z*8 (counts), with the element size of the rows the kernel really streams.  `achieved` / `frac` are for the dominant
+kernel (the hourly sampler launch: B over its hipEvent duration); `whole_resample` is 8(d)'s own figure, T*B over the wall
+time of a step; `kernels` lists every hourly kernel of the step with its own bytes, duration and measured traffic.
 """
 import argparse
 import json
@@ -24,6 +29,7 @@ sys.path.insert(0, ROOT)
 TABLE_SEED = 0x5EED7AB1E
 SIM_SEED = 0x5EEDCA125
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+PROFILE_TAG = "round2"  # profiles/<tag>_traffic.json: PMC run of this same command (tools/collect_profiles.sh)
 
 
 def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
@@ -51,13 +57,13 @@ def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
     dt = time.perf_counter() - t0
     pk, dr, _ = O.histogram(Z, st, tr)
     # the same cars through the HIP path
-    C_total, cpz, begin, count = sampler.C_total, sampler.cars_per_zone, sampler.car_begin, sampler.car_count
+    C_total, cpz, begin, count, stride = sampler.C_total, sampler.cars_per_zone, sampler.car_begin, sampler.car_count, sampler.car_stride
     full = sampler.get_state()
     sampler.init_states(C_total, cpz, 0, n)
     sampler.set_state(zones[:n])
     r = sampler.resample(SIM_SEED)
     ok = bool(np.array_equal(r["parking"], pk.astype(np.int64)) and np.array_equal(r["driving"], dr.astype(np.int64)))
-    sampler.init_states(C_total, cpz, begin, count)
+    sampler.init_states(C_total, cpz, begin, count, car_stride=stride)
     sampler.set_state(full)
     # all-core best effort beside it (oracle fast twin: prebuilt CDF + binary search, OpenMP over cars)
     cdf = O.build_cdf(p_dest)
@@ -73,31 +79,37 @@ def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
             "counts_match_gpu": ok}
 
 
-def pmc_traffic(kernel, Z, cars_per_gpu):
-    """HBM bytes per sampler launch from the committed PMC run of this same command
+def pmc_traffic(Z, cars_per_gpu, skew):
+    """HBM bytes per launch of every hourly kernel from the committed PMC run of this same command
     (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in their own rocprofv3 passes, corrected as
-    MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  None when no run matches."""
-    if Z != 4096 or cars_per_gpu != 4096000:
-        return None, None
-    name = {0: "k_grouped_sample", 5: "k_grouped_sample", 2: "k_exact_sample", 1: "k_step_car"}[kernel]
-    for f in ("round1_gen6_traffic.json", "round1_final_traffic.json", "round1_bench_traffic.json", "round1_bench_zone_lds_traffic.json"):
-        path = os.path.join(ROOT, "profiles", f)
-        if os.path.exists(path):
-            for k, v in json.load(open(path)).items():
-                # (the grouped form of k_grouped_sample: last template argument true; the plain form only runs the last hour)
-                if name in k and v.get("launches", 0) > 0 and (name != "k_grouped_sample" or ", true>(" in k):
-                    return v["hbm_bytes_per_launch"], "profiles/" + f
-    return None, None
+    MI355X_MICROARCH.md prescribes; tools/summarize_profiles.py).  {} when no run matches this workload."""
+    if Z != 4096 or cars_per_gpu != 4096000 or skew:
+        return {}, None
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")
+    if not os.path.exists(path):
+        return {}, None
+    out = {}
+    for k, v in json.load(open(path)).items():
+        if v.get("launches", 0) <= 0:
+            continue
+        if "k_grouped_sample" in k and ", true>(" in k:   # (the grouped form; the plain form only runs hour 24)
+            out["sampler"] = v["hbm_bytes_per_launch"]
+        elif "k_grouped_place" in k:
+            out["place"] = v["hbm_bytes_per_launch"]
+    return out, "profiles/" + PROFILE_TAG + "_traffic.json"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--zones", type=int, default=4096)
     ap.add_argument("--cars-per-zone", type=int, default=1000, help="per GPU (weak scaling)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 car, 2 zone_lds, 5 zone_grouped")
+    ap.add_argument("--deal", default="interleaved", choices=["interleaved", "contiguous"], help="how cars are dealt over the ranks")
+    ap.add_argument("--skew", type=int, default=0, help="Q > 0: skewed destination popularity 1 / (Q + rank) (secondary figure; 32 ~ the "
+                                                        "most popular zone 26x the mean); 0: the flat headline tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -130,11 +142,11 @@ def main():
     Z, T = args.zones, 24
     cpz = args.cars_per_zone * world
     C = Z * cpz
-    ss = ShardedSampler(Z, T, rank=rank, world_size=world, device=local_rank)
+    ss = ShardedSampler(Z, T, rank=rank, world_size=world, device=local_rank, deal=args.deal)
     s = ss.s
     s.set_kernel(args.kernel)
-    s.synth_tables(TABLE_SEED)
-    begin, count = ss.init_states(C, cpz)
+    s.synth_tables(TABLE_SEED, skew_q=args.skew)
+    first, count = ss.init_states(C, cpz)
     s.solve_ivp_async(SIM_SEED)          # 23 untimed burn-in steps (main.jl:91-92)
     s.sync()
 
@@ -144,53 +156,67 @@ def main():
         torch.cuda.synchronize()
 
     if rehearse and world > 1:  # gloo cannot reduce device tensors: bounce through the host
-        def resample_allreduce(seed):
+        def resample_allreduce_async(seed, travel=False):
             with torch.cuda.stream(ss.stream):
                 s.resample_dev(seed, ss.counts.data_ptr())
                 host = ss.counts.cpu()
                 dist.all_reduce(host)
                 ss.counts.copy_(host)
-            return ss.counts
-        ss.resample_allreduce = resample_allreduce
+            return ss.counts, 0
+        ss.resample_allreduce_async = resample_allreduce_async
+        ss.wait = lambda ticket: None
 
-    for _ in range(args.warmup):
-        ss.resample_allreduce(SIM_SEED)
+    def run_steps(k):
+        """k pipelined steps: the all-reduce of a step overlaps the kernels of the next one; returns the last count tensor"""
+        buf = None
+        for _ in range(k):
+            buf, _ = ss.resample_allreduce_async(SIM_SEED)
+        ss.synchronize()
+        return buf
+
+    counts = run_steps(args.warmup)
     barrier()
-    # The fixed-stride zone kernels flag a bucket that outgrew its region in the status word (summed over
-    # ranks by the all-reduce); the step is then invalid and the exact layout must be used instead.
+    # The grouped kernels flag a bucket / run that outgrew its region in the status word (summed over ranks by the
+    # all-reduce); the step is then invalid, the context doubles its regions when it next enqueues.
     kernel_used = args.kernel
-    for _ in range(5):  # an overflowed step is flagged; the context doubles its bucket regions when it next enqueues
-        if int(ss.counts[-1].item()) == 0:
+    for _ in range(6):
+        if counts is None or int(counts[-1].item()) == 0:
             break
-        for _ in range(max(args.warmup, 1)):
-            ss.resample_allreduce(SIM_SEED)
+        counts = run_steps(max(args.warmup, 2))
         barrier()
-    if int(ss.counts[-1].item()) != 0:
+    if counts is not None and int(counts[-1].item()) != 0:
         kernel_used = 2
         s.set_kernel(kernel_used)
-        for _ in range(max(args.warmup, 1)):
-            ss.resample_allreduce(SIM_SEED)
+        counts = run_steps(max(args.warmup, 1))
         barrier()
     if kernel_used == 0:
         kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
     # hipEvents on the launch stream around every 7th hourly sampler launch of the timed region (7 is
     # coprime to 24, so every hour of the day is sampled).  Bracketing every launch was measured to put
     # two ~5 us bubbles around each of them: 12 % of the step.
-    s.set_profile(True, stride=7)
+    s.set_profile(True, stride=7, kernel=0)
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ss.resample_allreduce(SIM_SEED)
+    counts = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = s.last_kernel_ms()
+    sampler_ms = s.last_kernel_ms()
     s.set_profile(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    parking, driving, _ = cpm.distributed.split_counts(ss.counts, Z, T)
+    parking, driving, _ = cpm.distributed.split_counts(counts, Z, T)
     assert (parking.sum(axis=0) == C).all(), "every hour must hold all C cars"
+
+    # the other hourly kernel of the step, timed the same way outside the headline's timed region
+    place_ms = []
+    if kernel_used in (0, 5):
+        s.set_profile(True, stride=7, kernel=1)
+        run_steps(max(8, min(args.steps, 40)))
+        place_ms = s.last_kernel_ms()
+        s.set_profile(False)
 
     # secondary figure (BASELINE.md 3): the whole main.jl:88-95 sequence, initializestates -> 23-hour
     # IVP -> 24-hour resample, 47 car-steps per car; outside the headline's timed region
@@ -202,16 +228,35 @@ def main():
         with torch.cuda.stream(ss.stream):
             s.solve_ivp_async(SIM_SEED)
         ss.resample_allreduce(SIM_SEED)
+    ss.synchronize()
     barrier()
     dt_full = (time.perf_counter() - t0) / reps
 
     if rank == 0:
+        import numpy as np
         car_steps = C * T
+        ms_per_step = dt / args.steps * 1e3
         alg_bytes = s.algorithmic_bytes_per_hour()
-        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        avg_ms = sum(sampler_ms) / max(len(sampler_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(kernel_used, Z, count)
+        traffic, traffic_src = pmc_traffic(Z, count, args.skew)
         f64_bytes = Z * Z * 8 + Z * 8 + count * 8 + 2 * Z * 8  # SURVEY.md 8(d) with the reference's 8-byte rows
+        drivers_per_hour = float(driving.sum()) / T / world       # this GPU's share
+        place_bytes = int(drivers_per_hour * 8 + Z * 32 * 4 + Z * 4)  # packed driver in (4 B) + id out (4 B), run lengths, bucket sizes
+        place_avg = sum(place_ms) / max(len(place_ms), 1)
+        whole = T * alg_bytes / (ms_per_step * 1e-3) / 1e9
+
+        def kernel_entry(name, what, nbytes, ms, n, tr):
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "what": what, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches_timed": n,
+                    "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
+                    "traffic_over_algorithmic": (tr / nbytes) if tr and nbytes else None}
+        kernels = [kernel_entry("k_grouped_sample" if kernel_used in (0, 5) else {1: "k_step_car", 2: "k_exact_sample"}[kernel_used],
+                                "Bernoulli + categorical draw of every car, stayers compacted, drivers into runs, zone x hour counts",
+                                alg_bytes, avg_ms, len(sampler_ms), traffic.get("sampler"))]
+        if place_ms:
+            kernels.append(kernel_entry("k_grouped_place", "drivers from the runs into next hour's buckets (not part of 8(d)'s compulsory bytes: "
+                                        "its ids are counted with the sampler's C_g*8)", place_bytes, place_avg, len(place_ms), traffic.get("place")))
         out = {
             "metric": "car-steps/sec at Z=4,096, 1k cars/zone; 1/2/4/8 MI355X + %HBM roofline",
             "value": car_steps * args.steps / dt,
@@ -219,25 +264,31 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",  # the contract's arithmetic (f64 CDF compare, 53-bit draws); the default kernel evaluates it on 32-bit high words
                              # and 64-bit integers with an exact f64 fallback, bit-identical by construction
             "data": "synthetic" + (" (REHEARSAL: gloo, shared GPU -- not a measurement)" if rehearse else ""),
-            "config": {"workload": f"synthetic dense p_dest, Z={Z} zones, {cpz} cars/zone (C={C}), T={T} h resample "
-                                   f"from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
+            "config": {"workload": f"synthetic {'skewed (destination popularity 1/(%d+rank))' % args.skew if args.skew else 'dense'} p_dest, Z={Z} zones, "
+                                   f"{cpz} cars/zone (C={C}), T={T} h resample from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
-                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 5: "zone_grouped"}[kernel_used] + ("" if kernel_used == args.kernel else " (not the requested one: AUTO's choice or overflow fallback)"),
-                       "bucket_region_x_mean": s.get_info(2),
-                       "parallelism": f"car-sharded x{world}, one RCCL all-reduce of int64[{2 * T * Z + 2}]",
+                       "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 5: "zone_grouped"}[kernel_used]
+                       + ("" if kernel_used == args.kernel else " (not the requested one: AUTO's choice or overflow fallback)"),
+                       "bucket_region_x_mean": s.get_info(2), "largest_bucket_x_mean": float(parking.max()) / (C / Z),
+                       "parallelism": f"cars dealt {args.deal} over {world} rank(s), one RCCL all-reduce of int64[{2 * T * Z + 2}] per step, "
+                                      f"double-buffered (overlaps the next step's kernels)",
                        "table_seed": hex(TABLE_SEED), "sim_seed": hex(SIM_SEED),
                        "device": cpm.device_info(local_rank)["name"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "hourly sampler launch", "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": avg_ms, "launches_timed": len(kernel_ms),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("sampler"), "traffic_source": traffic_src,
+                         "kernel": "hourly sampler launch (dominant kernel): algorithmic bytes of one launch / its hipEvent duration",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": len(sampler_ms),
+                         "whole_resample": {"what": "SURVEY.md 8(d): T x algorithmic bytes per launch / wall time of a step (every kernel of the step "
+                                                    "in the denominator)", "achieved": whole, "frac": whole / HBM_PEAK_GBS,
+                                            "f64_equivalent_frac": T * f64_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "kernels": kernels,
                          "note": "algorithmic bytes use the element size the kernel streams (SURVEY.md 8d: substitute the variant's true "
                                  "size): on the default grouped path a row is a pack of 4-byte CDF high words plus a 2-byte guide entry per "
                                  "four destinations, not 8-byte f64; f64_equivalent prices the same launch at the reference's 8-byte rows",
@@ -247,7 +298,7 @@ def main():
             "full_pipeline": {"value": C * (2 * T - 1) / dt_full, "unit": "car-steps/s", "ms": dt_full * 1e3,
                               "what": "initializestates + 23-hour IVP + 24-hour resample (main.jl:88-95), 47 car-steps per car"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.skew:
             out["cpu_baseline"] = cpu_baseline(s, Z, T, min(count, 65536), args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ss.close()

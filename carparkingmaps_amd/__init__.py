@@ -10,7 +10,7 @@ from ._lib import (CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_GROUPED, CPM
                    CpmError)
 from .sampler import Sampler, device_count, device_info
 from .reference_api import (DeviceArray, Params, averagedrivingtime, correctparameters, createdatamatrix, createpdestin,
-                            createpdrive, createresultsdirectory, initializestates, params, processgeodata, release,
+                            createpdrive, createresultsdirectory, initializestates, invalidate, params, processgeodata, release,
                             resampling, run_dataset, saveparameters, saveresults, solveinitialvalueproblem,
                             zone_hour_counts)
 
@@ -19,5 +19,5 @@ __all__ = [
     "CPM_KERNEL_ZONE_LDS", "CPM_KERNEL_ZONE_GROUPED", "Params", "params", "createpdrive", "createpdestin", "initializestates",
     "solveinitialvalueproblem", "resampling", "averagedrivingtime", "correctparameters", "saveresults",
     "zone_hour_counts", "run_dataset", "release", "createdatamatrix", "processgeodata", "createresultsdirectory",
-    "saveparameters", "DeviceArray",
+    "saveparameters", "DeviceArray", "invalidate",
 ]

@@ -20,13 +20,13 @@ SYMBOLS = [
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
     "cpm_debug_categorical", "cpm_createdatamatrix_rows", "cpm_createdatamatrix_csv", "cpm_get_datamatrix",
     "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv", "cpm_set_distance", "cpm_get_info",
-    "cpm_init_states_strided",
+    "cpm_init_states_strided", "cpm_synth_tables_skewed",
 ]
 
 CPM_FLAG_TRAVEL = 1
 CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
 CPM_KERNEL_ZONE_GROUPED = 5
-CPM_OPT_KERNEL, CPM_OPT_PROFILE = 1, 2
+CPM_OPT_KERNEL, CPM_OPT_PROFILE, CPM_OPT_PROFILE_KERNEL = 1, 2, 3
 
 _lib = None
 
@@ -93,6 +93,7 @@ def load():
     L.cpm_resample_dev.argtypes = [vp, u64, u32, vp]
     L.cpm_solve_ivp_async.argtypes = [vp, u64]
     L.cpm_synth_tables.argtypes = [vp, u64]
+    L.cpm_synth_tables_skewed.argtypes = [vp, u64, i64]
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
     L.cpm_debug_categorical.argtypes = [vp, i64, i64, i64, vp, vp, C.POINTER(i32)]

@@ -71,6 +71,10 @@ struct cpm_ctx {
     int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
     double *d_dist = nullptr;    // [Z][Z]
+    double2 *d_tt = nullptr;          // [T][Z][Z] (mean, std) origin-major: what the grouped path's travel kernel gathers from (cpm_grouped.h)
+    bool tt_valid = false;
+    double *d_pdrive_mean = nullptr;  // [T][Z] mean_sum of createpdrive (src/createpdrive.jl:10-21): depends on datamatrix and dist only,
+    bool pdrive_mean_valid = false;   // so the model-selection sweep (p_min, p_max, e_drive vary) computes it once
     bool have_pdrive = false, have_cdf = false, have_dmat = false, have_dist = false;
     bool have_dm() const { return have_dmat && have_dist; }
     // cars
@@ -91,17 +95,18 @@ struct cpm_ctx {
     // absorb: the status word of every grouped step is copied to pinned host memory behind the step and looked at, without
     // waiting, when the next step is enqueued (the overflowed step itself is flagged in its own status word).
     bool grouped_overflowed = false;
-    long long *h_status = nullptr;      // pinned
+    long long *h_status = nullptr;      // pinned [2]: status word, largest heavy bucket of the step (GroupedWork::maxn)
     hipEvent_t status_ev = nullptr;
     bool status_pending = false;
     // An IVP enqueued on the grouped layout writes the new state beside the old one; it is committed (or repeated) by
     // finish_ivp() before anything reads or replaces the state or the tables.
     bool ivp_pending = false;
     uint64_t ivp_seed = 0;
-    long long *h_ivp_status = nullptr;  // pinned
+    long long *h_ivp_status = nullptr;  // pinned [2], likewise
     // options
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
+    int prof_what = CPM_PROFILE_SAMPLER;  // CPM_OPT_PROFILE_KERNEL
     int prof_stride = 1;      // bracket every prof_stride-th hourly sampler launch
     int64_t prof_seen = 0;    // sampler launches since profiling was switched on
     bool prof_open = false;
@@ -225,7 +230,7 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
     tb.last = c->d_last;
     tb.thr = c->d_thr;
     tb.cdf = c->d_cdf;
-    tb.dm = c->d_dm;
+    tb.tt = c->d_tt;
     tb.Z = static_cast<int>(c->Z);
     tb.Zp = c->Zp;
     tb.Zq = c->Zq;
@@ -235,8 +240,9 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
 
 constexpr int kMaxProf = 8192;
 
-void prof_begin(cpm_ctx *c)
+void prof_begin(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
 {
+    if (what != c->prof_what) return;
     c->prof_open = false;
     if (!c->profile || c->n_prof >= kMaxProf) return;
     if ((c->prof_seen++ % c->prof_stride) != 0) return;  // an event pair costs ~2 x 5 us of stream bubbles: sample
@@ -250,9 +256,9 @@ void prof_begin(cpm_ctx *c)
     (void)hipEventRecord(c->ev[k], c->stream);
 }
 
-void prof_end(cpm_ctx *c)
+void prof_end(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
 {
-    if (!c->prof_open) return;
+    if (what != c->prof_what || !c->prof_open) return;
     c->prof_open = false;
     size_t k = static_cast<size_t>(c->n_prof) * 2;
     if (c->ev.size() < k + 2) return;
@@ -316,7 +322,8 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
     if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
         c->status_pending = false;
-        if (*c->h_status != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
+        if (c->h_status[0] != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
+        c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));
     }
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
@@ -325,10 +332,20 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     if (kernel == CPM_KERNEL_ZONE_GROUPED) {
         if (!grouped_fits(c, c->zg.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR)");
+        if (travel && !c->tt_valid) {  // the travel table of the current datamatrix, once
+            const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
+            if (!c->d_tt) HIP_TRY(hipMalloc(&c->d_tt, sizeof(double2) * cells));
+            hipLaunchKernelGGL(cpm::k_build_travel_table, dim3(nblk(c->Z, cpm::kTtTile), nblk(c->Z, cpm::kTtTile), static_cast<unsigned>(c->T)),
+                               dim3(cpm::kTtTile * 8), 0, c->stream, c->d_dm, c->d_tt, static_cast<int>(c->Z), static_cast<int>(c->T));
+            HIP_TRY(hipGetLastError());
+            c->tt_valid = true;
+        }
         int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, travel, d_counts, c->cu_count,
-                                      [&](int) { prof_begin(c); }, [&](int) { prof_end(c); }, g_last_error);
+                                      [&](int what) { prof_begin(c, what); }, [&](int what) { prof_end(c, what); }, g_last_error);
         if (rc == CPM_OK && c->h_status && !c->status_pending) {
+            c->h_status[1] = 0;
             if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipMemcpyAsync(c->h_status + 1, c->zg.maxn, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                 hipEventRecord(c->status_ev, c->stream) == hipSuccess)
                 c->status_pending = true;
         }
@@ -336,7 +353,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     }
     if (kernel == CPM_KERNEL_ZONE_LDS) {
         return cpm::exact_run(c->zx, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp, static_cast<int>(c->T), c->n, c->cars,
-                              c->d_zone0, seed, travel, c->d_dm, d_counts, c->cu_count, [&](int) { prof_begin(c); }, [&](int) { prof_end(c); },
+                              c->d_zone0, seed, travel, c->d_dm, d_counts, c->cu_count, [&](int what) { prof_begin(c, what); }, [&](int what) { prof_end(c, what); },
                               g_last_error);
     }
     int32_t rc = ensure_rec(c);
@@ -376,7 +393,9 @@ int32_t ivp_grouped(cpm_ctx *c, uint64_t seed)
     int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, false, c->d_counts, c->cu_count,
                                   [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp);
     if (rc != CPM_OK) return rc;
+    c->h_ivp_status[1] = 0;
     HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_ivp_status + 1, c->zg.maxn, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return CPM_OK;
 }
 
@@ -387,7 +406,8 @@ int32_t finish_ivp(cpm_ctx *c)
     if (!c->ivp_pending) return CPM_OK;
     c->ivp_pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (*c->h_ivp_status == 0) {
+    c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]));
+    if (c->h_ivp_status[0] == 0) {
         std::swap(c->d_zone0, c->d_ztmp);
         HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
         return CPM_OK;
@@ -398,7 +418,8 @@ int32_t finish_ivp(cpm_ctx *c)
         int32_t rc = ivp_grouped(c, c->ivp_seed);
         if (rc != CPM_OK) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (*c->h_ivp_status == 0) {
+        c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]));
+        if (c->h_ivp_status[0] == 0) {
             std::swap(c->d_zone0, c->d_ztmp);
             HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
             return CPM_OK;
@@ -483,10 +504,11 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(long long));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 2 * sizeof(long long));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming);
-    if (e == hipSuccess) *c->h_status = 0;
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_ivp_status), sizeof(long long));
+    if (e == hipSuccess) c->h_status[0] = c->h_status[1] = 0;
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_ivp_status), 2 * sizeof(long long));
+    if (e == hipSuccess) c->h_ivp_status[0] = c->h_ivp_status[1] = 0;
     if (e != hipSuccess) {
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
@@ -508,6 +530,8 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_thr);
     dfree(c->d_dm);
     dfree(c->d_dist);
+    dfree(c->d_pdrive_mean);
+    dfree(c->d_tt);
     dfree(c->d_zone0);
     dfree(c->d_ztmp);
     dfree(c->d_rec);
@@ -532,6 +556,10 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         if (value != CPM_KERNEL_AUTO && value != CPM_KERNEL_CAR && value != CPM_KERNEL_ZONE_LDS && value != CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
+    case CPM_OPT_PROFILE_KERNEL:
+        if (value < CPM_PROFILE_SAMPLER || value > CPM_PROFILE_TRAVEL) return fail(CPM_ERR_ARG, "profile kernel %lld", (long long)value);
+        c->prof_what = static_cast<int>(value);
+        return CPM_OK;
     case CPM_OPT_PROFILE:
         c->profile = value != 0;
         c->prof_stride = value > 1 ? static_cast<int>(value) : 1;
@@ -552,6 +580,9 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         return CPM_OK;
     case CPM_INFO_CAP_MULT:
         *value_out = c->zg.cap_mult;
+        return CPM_OK;
+    case CPM_INFO_PARTS:
+        *value_out = c->zg.parts;
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown info %d", what);
@@ -628,16 +659,19 @@ int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *d
         int32_t rc_ivp = finish_ivp(c);
         if (rc_ivp != CPM_OK) return rc_ivp;
     }
-    if (!datamatrix || !dist) return fail(CPM_ERR_ARG, "null datamatrix / dist");
+    if (!datamatrix) return fail(CPM_ERR_ARG, "null datamatrix");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T * 2;
     size_t dbytes = sizeof(double) * c->Z * c->Z;
     if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, bytes));
-    if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
+    if (dist && !c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
+    c->have_dmat = false;
+    c->tt_valid = false;
+    c->pdrive_mean_valid = false;
     HIP_TRY(hipMemcpyAsync(c->d_dm, datamatrix, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
+    if (dist) HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_dmat = true;
-    c->have_dist = true;
+    if (dist) c->have_dist = true;
     return CPM_OK;
 }
 
@@ -660,6 +694,8 @@ static int32_t datamatrix_from_device_rows(cpm_ctx *c, const double *d_raw, int6
     const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
     if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, sizeof(double) * cells * 2));
     c->have_dmat = false;
+    c->tt_valid = false;
+    c->pdrive_mean_valid = false;
     HIP_TRY(hipMemsetAsync(c->d_dm, 0, sizeof(double) * cells * 2, c->stream));  // zeros(number_zones, number_zones, T, 2) (:7)
     if (n == 0) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -793,6 +829,7 @@ int32_t cpm_set_distance_from_centroids(cpm_ctx *c, const double *centroid_lat, 
     dfree(d_ll);
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "distance matrix: %s", hipGetErrorString(e));
     c->have_dist = true;
+    c->pdrive_mean_valid = false;
     return CPM_OK;
 }
 
@@ -805,6 +842,7 @@ int32_t cpm_set_distance(cpm_ctx *c, const double *dist)
     HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_dist = true;
+    c->pdrive_mean_valid = false;
     return CPM_OK;
 }
 
@@ -828,17 +866,19 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
     if (!c->have_dm()) return fail(CPM_ERR_STATE, "build_p_drive: datamatrix and distance matrix first (cpm_set_datamatrix, or cpm_createdatamatrix_* + cpm_set_distance_from_centroids)");
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
-    double *d_ms = nullptr;
-    HIP_TRY(hipMalloc(&d_ms, bytes));
-    dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL(cpm::k_pdrive_mean, grid, dim3(64), 0, c->stream, c->d_dm, c->d_dist, d_ms, static_cast<int>(c->Z));
-    hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64)), dim3(64), 0, c->stream, d_ms, c->d_pdrive,
+    if (!c->d_pdrive_mean) HIP_TRY(hipMalloc(&c->d_pdrive_mean, bytes));
+    if (!c->pdrive_mean_valid) {  // the Z x Z x T pass over the datamatrix: once per datamatrix / distance matrix
+        dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
+        hipLaunchKernelGGL(cpm::k_pdrive_mean, grid, dim3(64), 0, c->stream, c->d_dm, c->d_dist, c->d_pdrive_mean, static_cast<int>(c->Z));
+        HIP_TRY(hipGetLastError());
+        c->pdrive_mean_valid = true;
+    }
+    hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64)), dim3(64), 0, c->stream, c->d_pdrive_mean, c->d_pdrive,
                        static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);
     hipError_t e = hipGetLastError();
     int32_t rc_thr = (e == hipSuccess) ? update_thr(c) : CPM_OK;
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dfree(d_ms);
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_drive: %s", hipGetErrorString(e));
     if (rc_thr != CPM_OK) return rc_thr;
     c->have_pdrive = true;
@@ -893,9 +933,12 @@ int32_t cpm_get_cdf_row(cpm_ctx *c, int64_t origin1, int64_t hour1, double *out)
     return CPM_OK;
 }
 
-int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
+int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed) { return cpm_synth_tables_skewed(c, table_seed, 0); }
+
+int32_t cpm_synth_tables_skewed(cpm_ctx *c, uint64_t table_seed, int64_t skew_q)
 {
     CTX_TRY(c);
+    if (skew_q < 0 || (skew_q > 0 && c->Z % 7919 == 0)) return fail(CPM_ERR_ARG, "synth_tables: skew %lld", (long long)skew_q);
     {   // a pending asynchronous IVP must be committed (or, after an overflow, repeated) on the tables it was enqueued with
         int32_t rc_ivp = finish_ivp(c);
         if (rc_ivp != CPM_OK) return rc_ivp;
@@ -913,7 +956,7 @@ int32_t cpm_synth_tables(cpm_ctx *c, uint64_t table_seed)
     double *d_p = nullptr;
     HIP_TRY(hipMalloc(&d_p, sizeof(double) * c->Z * c->Z * c->T));
     dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z), table_seed);
+    hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z), table_seed, skew_q);
     int32_t rc = CPM_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "synth_tables: %s", hipGetErrorString(e));
@@ -1055,6 +1098,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         int64_t status = 0;
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));  // (how the next grouped step is launched)
         c->status_pending = false;  // this step's status word is dealt with here: resample_enqueue must not grow the regions for it again
         // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
         while (status != 0 && rc == CPM_OK && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
@@ -1062,6 +1106,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
             if (rc != CPM_OK) break;
             HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));
             c->status_pending = false;
         }
         if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout
@@ -1169,5 +1214,28 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
     if (n_exact_out) *n_exact_out = h_n;
     return CPM_OK;
 }
+
+#ifdef CPM_DIAGNOSTIC
+// diagnostic builds only (tools/place_stamps.py): a side buffer for the s_memtime stamps of the placing kernel; n_blocks x 8 words
+int32_t cpm_diag_place_stamps(cpm_ctx *c, unsigned long long *host_out_or_null, int64_t n_blocks)
+{
+    CTX_TRY(c);
+    static unsigned long long *d_buf = nullptr;
+    static int64_t cap = 0;
+    if (!host_out_or_null) {  // arm
+        if (cap < n_blocks) {
+            if (d_buf) (void)hipFree(d_buf);
+            HIP_TRY(hipMalloc(&d_buf, sizeof(unsigned long long) * 8 * n_blocks));
+            cap = n_blocks;
+        }
+        HIP_TRY(hipMemset(d_buf, 0, sizeof(unsigned long long) * 8 * n_blocks));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(cpm::g_place_stamps), &d_buf, sizeof(d_buf)));
+        return CPM_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host_out_or_null, d_buf, sizeof(unsigned long long) * 8 * std::min(n_blocks, cap), hipMemcpyDeviceToHost));
+    return CPM_OK;
+}
+#endif
 
 }  // extern "C"

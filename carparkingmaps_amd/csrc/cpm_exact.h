@@ -503,14 +503,14 @@ int32_t exact_run(ExactWork &w, hipStream_t stream, const double *d_pdrive, cons
         const double *pd = d_pdrive + static_cast<size_t>(t) * Z;
         const double *cdf = d_cdf + static_cast<size_t>(t) * Z * Zp;
         const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
-        prof_begin(t);
+        prof_begin(CPM_PROFILE_SAMPLER);
         if (travel)
             exact_launch_sample<true>(stream, ids, off, w.dest, pd, cdf, Z, Zp, cars, step, seed, parking + static_cast<size_t>(t) * Z,
                                       driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum);
         else
             exact_launch_sample<false>(stream, ids, off, w.dest, pd, cdf, Z, Zp, cars, step, seed, parking + static_cast<size_t>(t) * Z,
                                        driving + static_cast<size_t>(t) * Z, d_dm, T, t, tt_sum);
-        prof_end(t);
+        prof_end(CPM_PROFILE_SAMPLER);
         if (ivp || t + 1 < T) {  // resampling: hour T's transition is sampled but never applied (src/resampling.jl:81-83)
             uint32_t *cur = w.cursor + static_cast<size_t>(t) * Z;
             uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;

@@ -208,8 +208,11 @@ struct GroupedArgs {
     uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
     uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
     unsigned long long *parking_t, *driving_t, *status;
+    uint32_t *maxn;           // largest bucket seen above 2 * CPT * BLOCK cars (atomicMax; the context sizes `parts` from it)
     int Z, Zp, Zq, G;
     uint32_t cap, scap, idbits, gshift, step;
+    uint32_t parts;           // 1: this launch walks whole buckets (overflow rounds of BLOCK cars).  > 1: it takes the first CPT * BLOCK
+                              // cars of every bucket and k_grouped_sample_heavy, launched behind it with parts - 1 blocks per zone, the rest
     CarIndex cars;
     uint64_t seed;
 };
@@ -354,8 +357,26 @@ constexpr int kStage = CPM_STAGE;
 #define CPM_WPS 6  // waves per SIMD the register allocator must leave room for (see profiles/round1_notes.md, round2_notes.md)
 #endif
 
+#ifdef CPM_NSGPR  // tuning builds: cap the scalar registers (256-thread workgroups per CU <= floor(800 / (ceil(sgpr / 16) * 16 + 16)))
+#define CPM_SGPR_ATTR __attribute__((amdgpu_num_sgpr(CPM_NSGPR)))
+#else
+#define CPM_SGPR_ATTR
+#endif
+// Diagnostic builds (-DCPM_DIAGNOSTIC, never the product): s_memtime stamps of thread 0 of every placing block into a side buffer
+#ifdef CPM_DIAGNOSTIC
+__device__ unsigned long long *g_place_stamps = nullptr;  // [blocks][8], set by cpm_diag_place_stamps
+#define CPM_PSTAMP(k)                                                                                              \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && g_place_stamps) g_place_stamps[static_cast<size_t>(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define CPM_PSTAMP(k) \
+    do {              \
+    } while (0)
+#endif
+
 template <int BLOCK, int CPT, int NQ, bool GROUPED>
-__global__ __launch_bounds__(BLOCK, CPM_WPS) void k_grouped_sample(GroupedArgs a)
+__global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample(GroupedArgs a)
 {
     extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
     __shared__ uint32_t s_ndrive, s_nstay;
@@ -382,11 +403,14 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) void k_grouped_sample(GroupedArgs a
     }
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
-    const uint32_t n = min(n_raw, cap);
+    const uint32_t n_all = min(n_raw, cap);
+    // a bucket beyond CPT * BLOCK cars: walked here BLOCK cars at a time (parts == 1), or left to the heavy kernel (parts > 1)
+    const uint32_t n = (a.parts > 1) ? min(n_all, static_cast<uint32_t>(CPT * BLOCK)) : n_all;
     if (tid == 0) {
-        a.parking_t[z] = n;  // every car present at hour t, drivers included (src/saveresults.jl:12)
+        a.parking_t[z] = n_all;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         s_ndrive = 0;
         s_nstay = 0;
+        if (n_all > 2u * CPT * BLOCK) atomicMax(a.maxn, n_all);  // (never on flat tables: a bucket twice the slots of its workgroup)
     }
     if (tid < kGroups) gb[tid] = 0;
     if (n == 0) {  // driving_t[z] stays 0 (zeroed by the caller)
@@ -527,6 +551,125 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) void k_grouped_sample(GroupedArgs a
     }
 }
 
+// The rest of the buckets that hold more than CPT * BLOCK cars (real Uber Movement tables are peaky: a central zone can hold tens of
+// times the mean, and one workgroup walking it BLOCK cars at a time is the tail of the whole launch).  Launched behind
+// k_grouped_sample when the context has seen such buckets (GroupedArgs::parts > 1), with parts - 1 blocks per zone: block (z, q)
+// takes the chunks q, q + (parts - 1), ... of CPT * BLOCK cars behind the first one and exits at once when there is none (nearly
+// all of them do).  It shares the zone's outputs with the first workgroup and its sibling blocks, which have already written theirs
+// or are writing them now: stayers take their slots in next hour's bucket with one global ticket per wave (cnt_next[z], which the
+// placing kernel goes on adding to), drivers are ranked per chunk in LDS and reserve their range of the zone's runs with one
+// global atomic per (chunk, destination group) on the run length, driving counts are added.  Order inside buckets and runs is
+// arbitrary anyway (a car's draws depend on its id only, counts are order-free).
+template <int BLOCK, int CPT, int NQ>
+__global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a)
+{
+    extern __shared__ uint32_t pack[];
+    __shared__ uint32_t gb[kGroups], gbase[kGroups];
+    const int Z = a.Z;
+    const int z = blockIdx.x;
+    const uint32_t q = blockIdx.y, nq = a.parts - 1u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr uint32_t L = CPT * BLOCK;
+    const uint32_t cap = a.cap;
+    const uint32_t n = min(a.cnt[z], cap);
+    const uint32_t start0 = L * (1u + q);
+    if (start0 >= n) return;
+    const uint32_t b = static_cast<uint32_t>(z) * cap;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    const double last = a.last_t[z];
+    const long long thr = a.thr_t[z];
+    pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
+    if (tid < kGroups) gb[tid] = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
+    const uint32_t hi_last = hi[Z - 1];
+    const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
+    uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
+    uint32_t nd = 0;
+    for (uint32_t start = start0; start < n; start += L * nq) {  // (block-uniform trips)
+        uint32_t id[CPT], dest[CPT], clo[CPT], khi[CPT];
+        bool valid[CPT], drive[CPT], want[CPT], ok[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const uint32_t s = start + static_cast<uint32_t>(tid + c * BLOCK);
+            valid[c] = s < n;
+            id[c] = a.ids[b + min(s, n - 1u)];
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            long long kb;
+            car_draw_words(a.seed, a.cars.global(id[c]), a.step, kb, clo[c], khi[c]);
+            drive[c] = valid[c] & (kb <= thr);
+            want[c] = drive[c] & (last != 0.0);
+        }
+        pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+        bool anyx = false;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
+            anyx |= want[c] & !ok[c];
+        }
+        if (__builtin_expect(__any(anyx), 0)) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
+        }
+        // stayers: one global ticket per wave
+        unsigned long long mS[CPT];
+        uint32_t total = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            mS[c] = __ballot(valid[c] & !drive[c]);
+            total += static_cast<uint32_t>(__popcll(mS[c]));
+        }
+        uint32_t bS = 0;
+        if (lane == 0 && total) {
+            bS = atomicAdd(&a.cnt_next[z], total);
+            if (bS + total > cap) atomicOr(a.status, 2ull);
+        }
+        bS = __shfl(bS, 0, 64);
+        uint32_t rank[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+            nd += drive[c] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const uint32_t p = bS + static_cast<uint32_t>(__popcll(mS[c] & below));
+            if ((valid[c] & !drive[c]) && p < cap) stay_out[p] = id[c];
+            bS += static_cast<uint32_t>(__popcll(mS[c]));
+        }
+        __syncthreads();  // the chunk's ranks are final
+        if (tid < kGroups) {
+            const uint32_t c = gb[tid];
+            uint32_t base = 0;
+            if (c) {
+                base = atomicAdd(&a.cntg[static_cast<size_t>(z) * kGroups + tid], c);
+                if (base + c > a.scap) atomicOr(a.status, 2ull);
+            }
+            gbase[tid] = base;
+            gb[tid] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (drive[c]) {
+                const uint32_t g = dest[c] >> a.gshift;
+                const uint32_t p = gbase[g] + rank[c];
+                if (p < a.scap) runs[g * a.scap + p] = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+            }
+        }
+        // (the next chunk writes gbase only behind its first barrier, which every thread reaches after these reads)
+    }
+    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+    if (lane == 0 && nd) atomicAdd(&a.driving_t[z], static_cast<unsigned long long>(nd));
+}
+
 // ------------------------------------------------------------------------------------------------ placing the drivers
 // Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share blockIdx % 8 (one XCD,
 // one L2: all writes to a bucket merge there; speed only, never correctness).  Block (g, j) takes the group-g runs of the origin
@@ -535,22 +678,33 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) void k_grouped_sample(GroupedArgs a
 constexpr int kPlaceBlock = 1024;
 constexpr int kPlaceSeg = kPlaceBlock / 16;
 
+// What bounds this kernel is the number of cache lines a store instruction touches (in-kernel stamps, profiles/round2_notes.md:
+// with every lane storing its own entry -- 64 buckets per wave-instruction -- issuing the stores took a third of a block's life).
+// So the block's entries are first sorted by destination zone in LDS (their rank inside the block is known from pass A, the
+// zones' offsets from a scan of the block's histogram) and then written out in that order: consecutive lanes write consecutive
+// slots of one bucket.
 template <int KRUNS, int KDEEP>
 __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
                                                                int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
                                                                uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
                                                                unsigned long long *status)
 {
-    // bins: entries held in registers per destination zone, then this block's base inside the zone's bucket;
-    // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those
-    __shared__ uint32_t bins[kMaxZonesPerGroup], tbins[kMaxZonesPerGroup];
-    const int tid = threadIdx.x;
+    constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;  // entries a block can hold in registers
+    // bins : per destination zone: entries held in registers (pass A), then their first index in the sorted list
+    // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those inside the bucket
+    // delta: (this block's first position inside the zone's bucket) - (the zone's first index in the sorted list)
+    __shared__ uint32_t bins[kMaxZonesPerGroup], tbins[kMaxZonesPerGroup], delta[kMaxZonesPerGroup];
+    __shared__ uint32_t wsum[kPlaceBlock / 64], s_total;
+    extern __shared__ uint32_t sorted_ids[];                                  // [kSlots] ids in destination order
+    uint16_t *sorted_zone = reinterpret_cast<uint16_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x % kGroups, j = blockIdx.x / kGroups;
     const int zg0 = g * zpg;
     const int nzl = max(0, min(zpg, Z - zg0));
     const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
     const int sub = tid >> 4, l16 = tid & 15;
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    CPM_PSTAMP(0);
     for (int k = tid; k < zpg; k += kPlaceBlock) {
         bins[k] = 0;
         tbins[k] = 0;
@@ -562,12 +716,13 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         const int zs = zs0 + sub + k * kPlaceSeg;
         const int zc = min(zs, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
-        c[k] = cntg[run];
+        c[k] = min(cntg[run], scap);  // (beyond scap only when the heavy kernel flagged an overflow: the step is repeated)
         if (zs >= zs1) c[k] = 0;
 #pragma unroll
         for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
     }
     __syncthreads();
+    CPM_PSTAMP(1);
     // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
@@ -583,29 +738,51 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
         for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) atomicAdd(&tbins[D[run * scap + i] >> idbits], 1u);
     }
+    CPM_PSTAMP(2);
     __syncthreads();
-    if (tid < nzl) {  // ticket: this block's range inside each bucket of the group
-        const uint32_t cr = bins[tid], ct = tbins[tid];
+    CPM_PSTAMP(3);
+    // ticket (this block's range inside each bucket of the group) and the zones' offsets in the sorted list (block scan of bins)
+    {
+        const bool zone = tid < nzl;
+        const uint32_t cr = zone ? bins[tid] : 0u, ct = zone ? tbins[tid] : 0u;
         uint32_t base = 0;
         if (cr + ct) {
             base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
             if (base + cr + ct > cap) atomicOr(status, 2ull);
         }
-        bins[tid] = base;
-        tbins[tid] = base + cr;
+        uint32_t incl = cr;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];  // (16 waves)
+        const uint32_t first = before + incl - cr;
+        if (zone) {
+            bins[tid] = first;
+            tbins[tid] = base + cr;
+            delta[tid] = base - first;  // (wraps; only base - first + index is used)
+        }
+        if (tid == kPlaceBlock - 1) s_total = before + incl;
     }
+    CPM_PSTAMP(4);
     __syncthreads();
-    // pass B: the ids move
+    CPM_PSTAMP(5);
+    // pass B: the entries held in registers go to their place in the sorted list ...
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
 #pragma unroll
         for (int d = 0; d < KDEEP; ++d)
             if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) {
                 const uint32_t dl = v[k][d] >> idbits;
-                const uint32_t p = bins[dl] + r[k][d];
-                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = v[k][d] & idmask;
+                const uint32_t li = bins[dl] + r[k][d];
+                sorted_ids[li] = v[k][d] & idmask;
+                sorted_zone[li] = static_cast<uint16_t>(dl);
             }
     }
+    // ... the entries beyond a run's first 16 * KDEEP straight to their buckets (rare on flat tables) ...
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
@@ -617,6 +794,15 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
             if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
         }
     }
+    __syncthreads();
+    // ... and the sorted list out: consecutive lanes, consecutive slots of one bucket
+    const uint32_t total = s_total;
+    for (uint32_t i = tid; i < total; i += kPlaceBlock) {
+        const uint32_t dl = sorted_zone[i];
+        const uint32_t p = delta[dl] + i;
+        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = sorted_ids[i];
+    }
+    CPM_PSTAMP(6);
 }
 
 // Blocks of the place kernel per destination group: at most 256 origin zones per block (one run per 16 lanes, four runs per
@@ -635,10 +821,20 @@ inline void grouped_launch_place(hipStream_t stream, const uint32_t *D, const ui
     const int bpg = place_bpg(Z);
     const int zps = (Z + bpg - 1) / bpg;
     const dim3 grid(kGroups * bpg), block(kPlaceBlock);
-    if (zps <= 4 * kPlaceSeg)
-        hipLaunchKernelGGL((k_grouped_place<4, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
-    else
-        hipLaunchKernelGGL((k_grouped_place<8, 2>), grid, block, 0, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next, ids_next, status);
+    static bool attr_done[64] = {};  // LDS opt-in for the larger form, once per device
+    if (zps <= 4 * kPlaceSeg) {
+        hipLaunchKernelGGL((k_grouped_place<4, 2>), grid, block, 6 * 4 * 2 * kPlaceBlock, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
+                           ids_next, status);
+    } else {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_place<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8 * 2 * kPlaceBlock);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL((k_grouped_place<8, 2>), grid, block, 6 * 8 * 2 * kPlaceBlock, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
+                           ids_next, status);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ travel times
@@ -646,8 +842,36 @@ inline void grouped_launch_place(hipStream_t stream, const uint32_t *D, const ui
 // sampler they cost it its occupancy: 138 VGPRs).  The sum is an integer in 2^-16 s units: order-free, bit-exact.
 constexpr int kTravelParts = 256;
 
+// The travel kernel gathers (mean, std) of its drivers' (origin, destination, hour) cells.  In the reference's datamatrix layout
+// [2][T][dest][origin] the two values lie Z*Z*T*8 B apart and consecutive destinations of one origin Z*8 B apart: two cache lines per
+// driver, none shared.  travel table = the same numbers as tt[t][origin][dest] = (mean, std): the drivers of an origin zone (one block)
+// read one 16-B cell each inside one contiguous Z*16-B row, so lines are shared and stay in L2.  Built once per datamatrix.
+constexpr int kTtTile = 32;
+__global__ __launch_bounds__(kTtTile * 8) void k_build_travel_table(const double *__restrict__ dm, double2 *__restrict__ tt, int Z, int T)
+{
+    __shared__ double2 tile[kTtTile][kTtTile + 1];
+    const int t = blockIdx.z;
+    const int o0 = blockIdx.x * kTtTile, d0 = blockIdx.y * kTtTile;
+    const int tx = threadIdx.x & (kTtTile - 1), ty = threadIdx.x / kTtTile;  // 32 x 8
+    const size_t sd_off = static_cast<size_t>(Z) * Z * T;
+    for (int r = ty; r < kTtTile; r += 8) {  // read: origin on the lane (the reference's fastest index)
+        const int o = o0 + tx, d = d0 + r;
+        double2 v = make_double2(0.0, 0.0);
+        if (o < Z && d < Z) {
+            const size_t cell = static_cast<size_t>(o) + static_cast<size_t>(Z) * (d + static_cast<size_t>(Z) * t);
+            v = make_double2(dm[cell], dm[cell + sd_off]);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < kTtTile; r += 8) {  // write: destination on the lane
+        const int o = o0 + r, d = d0 + tx;
+        if (o < Z && d < Z) tt[(static_cast<size_t>(t) * Z + o) * Z + d] = tile[tx][r];
+    }
+}
+
 struct TravelArgs {
-    const double *dm;
+    const double2 *tt_t;          // [Z][Z] (mean, std) of this hour, origin-major
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
     int T, t, gshift;
     uint32_t step;
@@ -685,7 +909,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
     // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
     constexpr int kTravelBatch = 4;
-    const size_t sd_off = static_cast<size_t>(Z) * Z * tr.T;
+    const double2 *tt_row = tr.tt_t + static_cast<size_t>(z) * Z;
     for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
         uint32_t w[kTravelBatch], dest[kTravelBatch];
         bool live[kTravelBatch];
@@ -705,9 +929,9 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
 #pragma unroll
         for (int u = 0; u < kTravelBatch; ++u) {
             const bool moving = live[u] && dest[u] != static_cast<uint32_t>(z);
-            const size_t cell = static_cast<size_t>(z) + static_cast<size_t>(Z) * (dest[u] + static_cast<size_t>(Z) * tr.t);
-            mean[u] = moving ? tr.dm[cell] : 0.0;
-            sd[u] = moving ? tr.dm[cell + sd_off] : 0.0;
+            const double2 cell = moving ? tt_row[dest[u]] : make_double2(0.0, 0.0);
+            mean[u] = cell.x;
+            sd[u] = cell.y;
         }
 #pragma unroll
         for (int u = 0; u < kTravelBatch; ++u) {
@@ -773,14 +997,56 @@ inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
     else grouped_launch_nq<GROUPED, CPT, 40>(a, lds, stream);
 }
 
+template <int CPT, int NQ>
+inline void grouped_launch_heavy_nq(const GroupedArgs &a, size_t lds, hipStream_t stream)
+{
+    if (lds > 48 * 1024) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample_heavy<kSampleBlock, CPT, NQ>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(a.Z, a.parts - 1), dim3(kSampleBlock), lds, stream, a);
+}
+
+template <int CPT>
+inline void grouped_launch_heavy_c(const GroupedArgs &a, hipStream_t stream)
+{
+    const int words = pack_row_words(a.Zq, a.G);
+    const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
+    const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (need <= 2) grouped_launch_heavy_nq<CPT, 2>(a, lds, stream);
+    else if (need <= 5) grouped_launch_heavy_nq<CPT, 5>(a, lds, stream);
+    else if (need <= 12) grouped_launch_heavy_nq<CPT, 12>(a, lds, stream);
+    else grouped_launch_heavy_nq<CPT, 40>(a, lds, stream);
+}
+
+inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2 : 4); }
+
+inline void grouped_launch_heavy(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+{
+    if (a.parts <= 1) return;
+    switch (grouped_cpt(mean)) {
+    case 1: grouped_launch_heavy_c<1>(a, stream); break;
+    case 2: grouped_launch_heavy_c<2>(a, stream); break;
+    default: grouped_launch_heavy_c<4>(a, stream); break;
+    }
+}
+
 // Cars per thread by the mean bucket size (cars of this GPU / zones): 256 x 4 slots for ~1000 cars per zone, 256 x 2 and 256 x 1
 // for smaller buckets (every slot runs Philox whether a car sits in it or not); larger buckets take the overflow rounds.
 template <bool GROUPED>
 inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_t stream)
 {
-    if (mean <= 224) grouped_launch_c<GROUPED, 1>(a, stream);
-    else if (mean <= 560) grouped_launch_c<GROUPED, 2>(a, stream);
-    else grouped_launch_c<GROUPED, 4>(a, stream);
+    switch (grouped_cpt(mean)) {
+    case 1: grouped_launch_c<GROUPED, 1>(a, stream); break;
+    case 2: grouped_launch_c<GROUPED, 2>(a, stream); break;
+    default: grouped_launch_c<GROUPED, 4>(a, stream); break;
+    }
 }
 
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
@@ -873,7 +1139,16 @@ struct GroupedWork {
     uint32_t *Dq = nullptr;                                      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;                                    // [Z][kGroups] run lengths
     unsigned long long *tt_part = nullptr;                       // [kTravelParts] partial travel-time sums, kept zero between resamples
+    uint32_t *maxn = nullptr;                                    // [1] largest heavy bucket (> 2 x the sampler workgroup's slots) of the current run
+    int parts = 1;                                               // workgroups per zone of the sampler: 1 + blocks of the heavy kernel (set_parts)
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
+
+    // what the last run saw -> how the next one is launched: enough workgroups per zone for the largest bucket, at most 32
+    void set_parts(uint32_t largest_heavy_bucket)
+    {
+        const int64_t slots = static_cast<int64_t>(grouped_cpt((n + Z - 1) / std::max(Z, 1))) * kSampleBlock;
+        parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(32, (largest_heavy_bucket + slots - 1) / slots)));
+    }
 
     void release()
     {
@@ -883,6 +1158,8 @@ struct GroupedWork {
         }
         if (tt_part) (void)hipFree(tt_part);
         tt_part = nullptr;
+        if (maxn) (void)hipFree(maxn);
+        maxn = nullptr;
         n = 0;
         buckets0_valid = false;
     }
@@ -915,6 +1192,7 @@ struct GroupedWork {
         alloc(&cntg, static_cast<size_t>(Z) * kGroups);
         if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
+        if (e == hipSuccess) e = hipMalloc(&maxn, sizeof(uint32_t));
         if (e != hipSuccess) release();
         return e;
     }
@@ -925,7 +1203,7 @@ struct GroupedTables {
     const double *last;      // [T][Z]
     const long long *thr;    // [T][Z]
     const double *cdf;       // [T][Z][Zp]
-    const double *dm;        // datamatrix (travel times) or nullptr
+    const double2 *tt;       // [T][Z][Z] travel table (k_build_travel_table) or nullptr
     int Z, Zp, Zq, T;
 };
 
@@ -958,6 +1236,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     unsigned long long *status = tt_sum + 1;
     e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w.maxn, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return hip_fail(e, "memset counters");
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
@@ -993,6 +1272,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.status = status;
+        a.maxn = w.maxn;
+        a.parts = grouped ? static_cast<uint32_t>(w.parts) : 1u;
         a.Z = Z;
         a.Zp = tb.Zp;
         a.Zq = tb.Zq;
@@ -1004,18 +1285,21 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.step = step;
         a.cars = cars;
         a.seed = seed;
-        prof_begin(t);
+        prof_begin(CPM_PROFILE_SAMPLER);
         if (grouped) grouped_launch_sample<true>(a, mean, stream);
         else grouped_launch_sample<false>(a, mean, stream);
-        prof_end(t);
+        prof_end(CPM_PROFILE_SAMPLER);
+        if (grouped) grouped_launch_heavy(a, mean, stream);
         if (!last_hour) {
+            prof_begin(CPM_PROFILE_PLACE);
             grouped_launch_place(stream, w.Dq, w.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next, ids_next, status);
+            prof_end(CPM_PROFILE_PLACE);
             ids = ids_next;
             cnt = cnt_next;
         }
         if (travel && grouped) {
             TravelArgs tr{};
-            tr.dm = tb.dm;
+            tr.tt_t = tb.tt + static_cast<size_t>(t) * Z * Z;
             tr.tt_part = w.tt_part;
             tr.T = T;
             tr.t = t;
@@ -1023,7 +1307,9 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.step = step;
             tr.cars = cars;
             tr.seed = seed;
+            prof_begin(CPM_PROFILE_TRAVEL);
             hipLaunchKernelGGL(k_grouped_travel, dim3(Z), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+            prof_end(CPM_PROFILE_TRAVEL);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
     }

@@ -130,9 +130,19 @@ __global__ void k_synth_p_drive(double *pdrive, int Z, int T, uint64_t table_see
     pdrive[i] = 0.1 + 0.8 * u;
 }
 
+// Destination popularity of the skewed synthetic tables: weight 1 / (q + rank(d)), rank a fixed scrambling of the zone ids
+// (Zipf-Mandelbrot; the shape of the reference's output_24_0.svg: a few destinations many times as likely as the mean).  q <= 0: flat.
+__host__ __device__ inline double synth_dest_weight(double u, int o, int d, int Z, int64_t skew_q)
+{
+    if (o == d) return 0.0;  // Uber rows have origin != destination (README.md:244)
+    double w = u * u;        // ((m - min) / (max - min))^2, src/createpdestin.jl:24
+    if (skew_q > 0) w = w / static_cast<double>(skew_q + (static_cast<int64_t>(d) * 7919 + 13) % Z);
+    return w;
+}
+
 // one thread per (origin, hour): sequential row sum, then the normalised row, written in
 // the reference's layout (origin fastest -> coalesced across the wave)
-__global__ void k_synth_p_dest(double *__restrict__ p, int Z, uint64_t table_seed)
+__global__ void k_synth_p_dest(double *__restrict__ p, int Z, uint64_t table_seed, int64_t skew_q)
 {
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     int t = blockIdx.y;
@@ -140,13 +150,12 @@ __global__ void k_synth_p_dest(double *__restrict__ p, int Z, uint64_t table_see
     double nf = 0.0;
     for (int d = 0; d < Z; ++d) {
         double u = table_uniform(table_seed, o, d, t, kStreamPDest);
-        double w = (o == d) ? 0.0 : u * u;
-        nf = nf + w;
+        nf = nf + synth_dest_weight(u, o, d, Z, skew_q);
     }
     double *dst = p + static_cast<size_t>(t) * Z * Z + o;
     for (int d = 0; d < Z; ++d) {
         double u = table_uniform(table_seed, o, d, t, kStreamPDest);
-        double w = (o == d) ? 0.0 : u * u;
+        double w = synth_dest_weight(u, o, d, Z, skew_q);
         if (nf > 0) w = w / nf;
         dst[static_cast<size_t>(d) * Z] = w;
     }

@@ -18,6 +18,7 @@ the per-point scalars are gathered at the end.  Points sharing e_dest share the 
 The reference's measured validation data (traffic_activity_measured.jld2, parking_density_measured.jld2)
 are not in the repository; callers pass their own vectors (tests use synthetic ones).
 """
+import zlib
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -165,21 +166,29 @@ def make_grid(e_drive=(0.25, 0.5, 1.0, 2.0), p_min=(0.0, 0.05, 0.1, 0.2), p_max=
     return [Point(a, b, c, d) for d in e_dest for a in e_drive for b in p_min for c in p_max]
 
 
-def points_of_rank(n_points, rank, world_size):
-    """Round-robin deal: independent points, no data-path collective."""
-    return list(range(rank, n_points, world_size))
+def points_of_rank(n_points, rank, world_size, order=None):
+    """Block deal: rank r takes the r-th of world_size contiguous slices of `order` (default 0 .. n_points-1).  Independent
+    points, no data-path collective.  With the points ordered by e_dest a rank's slice spans as few e_dest values as
+    possible, so it rebuilds the CDF and the row packs (Z x Z x T work) as rarely as possible."""
+    order = list(range(n_points)) if order is None else list(order)
+    base, rem = divmod(len(order), int(world_size))
+    begin = rank * base + min(rank, rem)
+    return order[begin:begin + base + (1 if rank < rem else 0)]
 
 
 def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True):
     """Evaluate this rank's share of `grid`; returns a list (on every rank when gather) of dicts with the
     per-point scalars, ordered like `grid`."""
-    mine = points_of_rank(len(grid), rank, world_size)
-    mine.sort(key=lambda i: (type(grid[i].e_dest).__name__, float(grid[i].e_dest)))   # share the CDF
+    by_e_dest = sorted(range(len(grid)), key=lambda i: (float(grid[i].e_dest), type(grid[i].e_dest).__name__, i))
+    mine = points_of_rank(len(grid), rank, world_size, by_e_dest)
     local = {}
     for i in mine:
         r = evaluator.evaluate(grid[i])
         local[i] = {k: v for k, v in r.items() if np.isscalar(v)}
         local[i]["driving_total"] = int(r["driving"].sum())
+        local[i]["hours_hold_all_cars"] = bool((r["parking"].sum(axis=0) == evaluator.C).all())
+        local[i]["parking_crc32"] = zlib.crc32(np.ascontiguousarray(r["parking"].ravel(order="F")).tobytes())
+        local[i]["driving_crc32"] = zlib.crc32(np.ascontiguousarray(r["driving"].ravel(order="F")).tobytes())
     if world_size > 1 and gather:
         import torch.distributed as dist
         parts = [None] * world_size

@@ -30,6 +30,7 @@ class Params:
     T: int = 24               # main.jl:42
     seed: int = 0x5EEDCA125
     device: int = 0
+    trust_unchanged: bool = False  # True: a host array at the same address with the same shape is taken to be unchanged (no content pass)
 
 
 params = Params()
@@ -58,15 +59,29 @@ def release():
     _last.clear()
 
 
-def _fingerprint(a):
+def invalidate():
+    """Forget what is resident on the devices: the next call uploads its host arrays whatever they hold."""
+    for d in _loaded.values():
+        d.clear()
+
+
+def _stamp(a):
+    """(address, shape, strides, content sum) of a host array.  The content sum is one pass over the WHOLE buffer (a wrapping
+    uint64 sum of its words, ~10 GB/s: far below the PCIe upload + table build it can save), so an array edited in place -- the
+    notebook's tuning loops do that -- never leaves stale tables on the device.  params.trust_unchanged skips the pass."""
     a = np.asarray(a)
-    flat = a.reshape(-1, order="A")
-    step = max(1, flat.size // 65536)
-    return (a.__array_interface__["data"][0], a.shape, float(np.nansum(flat[::step])), float(flat[-1]) if flat.size else 0.0)
+    head = (a.__array_interface__["data"][0], a.shape, a.strides, str(a.dtype))
+    if params.trust_unchanged:
+        return head + (None,)
+    if a.dtype.itemsize == 8 and (a.flags.f_contiguous or a.flags.c_contiguous):
+        words = a.reshape(-1, order="A").view(np.uint64)
+    else:
+        words = np.ascontiguousarray(a, dtype=np.float64).reshape(-1).view(np.uint64)
+    return head + (int(np.add.reduce(words, dtype=np.uint64)) if words.size else 0,)
 
 
 def _ensure(key, s, name, array, setter):
-    fp = _fingerprint(array)
+    fp = _stamp(array)
     if _loaded[key].get(name) != fp:
         setter(array)
         _loaded[key][name] = fp
@@ -133,7 +148,11 @@ def geojson_vertex_lists(features):
         pts = walk(coords, 1) if isinstance(coords, list) else []
         if len(pts) > 100000:
             raise IndexError("more than 100000 coordinates in one zone (BoundsError in the reference, :19-20)")
-        zones[zid] = ([p[0] for p in pts], [p[1] for p in pts])  # a later feature with the same id overwrites from column 1
+        lons, lats = [p[0] for p in pts], [p[1] for p in pts]
+        if zid in zones:  # a later feature with the same id overwrites the row from column 1 and leaves the old tail in place (:19-97: the
+            old = zones[zid]  # matrices are only ever assigned element by element)
+            lons, lats = lons + old[0][len(lons):], lats + old[1][len(lats):]
+        zones[zid] = (lons, lats)
     return number_zones, zones
 
 
@@ -214,16 +233,16 @@ def saveparameters(path_to_results, T, number_zones, cars_per_zone, C, e_drive, 
 
 # ------------------------------------------------------------------------------- tables
 def _use_dm(s, key, datamatrix, distance_matrix_km):
-    """Make `datamatrix` (+ the distance matrix when given) the arrays resident in the context."""
+    """Make `datamatrix` (+ the distance matrix when given) the arrays resident in the context; host arrays that are already
+    resident and unchanged (content pass, _stamp) are not uploaded again."""
+    if distance_matrix_km is not None and not isinstance(distance_matrix_km, DeviceArray):
+        _ensure(key, s, "dist", distance_matrix_km, s.set_distance)
+        _loaded[key].pop("dist_device", None)
     if isinstance(datamatrix, DeviceArray):
         if _loaded[key].get("dm_device") != datamatrix.serial:
             raise RuntimeError("this datamatrix is no longer resident: createdatamatrix() was called again for these zones")
-        if distance_matrix_km is not None and not isinstance(distance_matrix_km, DeviceArray):
-            _ensure(key, s, "dist", distance_matrix_km, s.set_distance)  # a host distance matrix beside the device datamatrix
         return
-    if isinstance(distance_matrix_km, DeviceArray):
-        distance_matrix_km = distance_matrix_km.numpy()
-    _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, distance_matrix_km))
+    _ensure(key, s, "dm", datamatrix, lambda a: s.set_datamatrix(a, None))  # (None: the resident distance matrix is kept)
     _loaded[key].pop("dm_device", None)
 
 
@@ -232,21 +251,17 @@ def createpdrive(datamatrix, distance_matrix_km, number_zones):
     s, key = _sampler(number_zones)
     _use_dm(s, key, datamatrix, distance_matrix_km)
     out = s.build_p_drive(params.p_min, params.p_max, params.e_drive, want=True)
-    _loaded[key]["p_drive"] = _fingerprint(out)
+    _loaded[key]["p_drive"] = _stamp(out)      # what the device holds IS this array
     return out
 
 
 def createpdestin(datamatrix, number_zones):
-    """src/createpdestin.jl:3-50 -> p_dest (Z, Z, T).  Needs the distance matrix only through the
-    datamatrix upload, so createpdrive (main.jl:82) is expected to have run first, as in main.jl."""
+    """src/createpdestin.jl:3-50 -> p_dest (Z, Z, T), from the datamatrix it is GIVEN (uploaded now unless it is the resident one,
+    unchanged)."""
     s, key = _sampler(number_zones)
-    if isinstance(datamatrix, DeviceArray):
-        _use_dm(s, key, datamatrix, None)
-    elif _loaded[key].get("dm") != _fingerprint(datamatrix):
-        raise RuntimeError("createpdestin: call createpdrive(datamatrix, distance_matrix_km, number_zones) "
-                           "first, as main.jl:82-85 does (it uploads datamatrix and the distance matrix)")
+    _use_dm(s, key, datamatrix, None)
     out = s.build_p_dest(params.e_dest, want=True)
-    _loaded[key]["p_dest"] = _fingerprint(out)
+    _loaded[key]["p_dest"] = _stamp(out)
     return out
 
 

@@ -60,8 +60,9 @@ class Sampler:
         _lib.check(self._L.cpm_get_info(self._h, int(what), C.byref(v)))
         return int(v.value)
 
-    def set_profile(self, on=True, stride=1):
-        """hipEvents around every `stride`-th hourly sampler launch (0 / False: off)."""
+    def set_profile(self, on=True, stride=1, kernel=0):
+        """hipEvents around every `stride`-th hourly launch of `kernel` (0 sampler, 1 place, 2 travel); on=False: off."""
+        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE_KERNEL, int(kernel)))
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(stride) if on else 0))
 
     def set_stream(self, hip_stream):
@@ -80,9 +81,10 @@ class Sampler:
         a = _f64(p_dest, (self.Z, self.Z, self.T))
         _lib.check(self._L.cpm_set_p_dest(self._h, _vp(a)))
 
-    def set_datamatrix(self, datamatrix, distance_matrix_km):
+    def set_datamatrix(self, datamatrix, distance_matrix_km=None):
+        """distance_matrix_km None: the distance matrix already resident (set_distance*) is kept."""
         a = _f64(datamatrix, (self.Z, self.Z, self.T, 2))
-        d = _f64(distance_matrix_km, (self.Z, self.Z))
+        d = None if distance_matrix_km is None else _f64(distance_matrix_km, (self.Z, self.Z))
         _lib.check(self._L.cpm_set_datamatrix(self._h, _vp(a), _vp(d)))
 
     def createdatamatrix_rows(self, rawdata):
@@ -130,8 +132,9 @@ class Sampler:
         _lib.check(self._L.cpm_build_p_dest(self._h, float(e_dest), is_int, _vp(out)))
         return out
 
-    def synth_tables(self, table_seed):
-        _lib.check(self._L.cpm_synth_tables(self._h, int(table_seed)))
+    def synth_tables(self, table_seed, skew_q=0):
+        """Procedural bench tables; skew_q > 0: destination popularity 1 / (skew_q + rank), see include/cpm.h."""
+        _lib.check(self._L.cpm_synth_tables_skewed(self._h, int(table_seed), int(skew_q)))
 
     def get_p_drive(self):
         out = np.zeros((self.Z, self.T), dtype=np.float64, order="F")

@@ -65,8 +65,12 @@ extern "C" {
                                    * staged by LDS-DMA, stayers kept by the sampler, drivers placed per destination group; two launches per hour */
 
 #define CPM_OPT_KERNEL 1
-#define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly sampler launch with hipEvents (an event
+#define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly launch of the profiled kernel with hipEvents (an event
                                    pair costs ~10 us of stream bubbles, so sample); 0: off */
+#define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
+#define CPM_PROFILE_SAMPLER 0   /*   the sampler (default; every kernel family has one) */
+#define CPM_PROFILE_PLACE 1     /*   the grouped path's placing kernel */
+#define CPM_PROFILE_TRAVEL 2    /*   the grouped path's travel-time kernel (CPM_FLAG_TRAVEL) */
 
 typedef struct cpm_ctx cpm_ctx;
 
@@ -87,6 +91,7 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
  * or run outgrew it) */
 #define CPM_INFO_KERNEL 1
 #define CPM_INFO_CAP_MULT 2
+#define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above twice a workgroup's slots was seen */
 int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own */
 int32_t cpm_set_stream(cpm_ctx *ctx, void *hip_stream);
@@ -100,7 +105,8 @@ int32_t cpm_set_p_drive(cpm_ctx *ctx, const double *p_drive);
  * accumulation of src/resampling.jl:39 */
 int32_t cpm_set_p_dest(cpm_ctx *ctx, const double *p_dest);
 /* uploads createdatamatrix's array (main.jl:79) and processgeodata's distance matrix
- * (main.jl:59); enables cpm_build_* and CPM_FLAG_TRAVEL */
+ * (main.jl:59); enables cpm_build_* and CPM_FLAG_TRAVEL.  dist may be NULL: the distance matrix
+ * already resident (cpm_set_distance*) is kept */
 int32_t cpm_set_datamatrix(cpm_ctx *ctx, const double *datamatrix, const double *dist);
 /* createdatamatrix(path_to_csv_data, number_zones) (src/createdatamatrix.jl:3-27; main.jl:79) without the
  * dense host array: the Z x Z x T x 2 datamatrix is built in HBM and stays there.
@@ -183,7 +189,10 @@ int32_t cpm_solve_ivp_async(cpm_ctx *ctx, uint64_t seed);
 /* procedural synthetic tables of SURVEY.md 8(d), generated on device (bench inputs):
  * p_drive = 0.1 + 0.8 u ; dense p_dest ~ u^2, zero diagonal, row-normalised */
 int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
-/* with CPM_OPT_PROFILE: durations (ms) of the hourly sampler kernels launched by
+/* the same with skewed destination popularity (bench.py --skew): weight u^2 / (skew_q + rank(d)), rank(d) = (7919 d + 13) mod Z
+ * -- a few destinations many times as likely as the mean, like real Uber Movement rows (README.md output_24_0.svg) */
+int32_t cpm_synth_tables_skewed(cpm_ctx *ctx, uint64_t table_seed, int64_t skew_q);
+/* with CPM_OPT_PROFILE: durations (ms) of the hourly launches of the profiled kernel (CPM_OPT_PROFILE_KERNEL) made by
  * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
  * stream); returns the number written through *n_out */
 int32_t cpm_last_kernel_ms(cpm_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);

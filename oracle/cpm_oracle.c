@@ -616,6 +616,13 @@ int orc_synth_p_drive(int64_t Z, int64_t T, uint64_t table_seed, double *p_drive
 
 int orc_synth_p_dest_dense(int64_t Z, int64_t T, uint64_t table_seed, double *p_dest)
 {
+    return orc_synth_p_dest_skewed(Z, T, table_seed, 0, p_dest);
+}
+
+/* skew_q > 0: destination popularity 1 / (skew_q + rank(d)), rank(d) = (7919 d + 13) mod Z (Zipf-Mandelbrot) */
+int orc_synth_p_dest_skewed(int64_t Z, int64_t T, uint64_t table_seed, int64_t skew_q, double *p_dest)
+{
+    if (skew_q < 0 || (skew_q > 0 && Z % 7919 == 0)) return ORC_ERR_BADARG;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int64_t t = 0; t < T; ++t)
         for (int64_t o = 0; o < Z; ++o) {
@@ -624,6 +631,7 @@ int orc_synth_p_dest_dense(int64_t Z, int64_t T, uint64_t table_seed, double *p_
                 double u, v;
                 table_uniforms(table_seed, (uint32_t)o, (uint32_t)d, (uint32_t)t, TS_PDEST, &u, &v);
                 double w = (o == d) ? 0.0 : u * u; /* ((m-min)/(max-min))^2, createpdestin.jl:24 */
+                if (skew_q > 0 && o != d) w = w / (double)(skew_q + (d * 7919 + 13) % Z);
                 p_dest[o + Z * (d + Z * t)] = w;
                 nf = nf + w; /* createpdestin.jl:31-35 */
             }

@@ -62,6 +62,7 @@ def lib():
                                vp, vp, vp, vp, C.c_int]
     L.orc_synth_p_drive.argtypes = [i64, i64, u64, _f64p]
     L.orc_synth_p_dest_dense.argtypes = [i64, i64, u64, _f64p]
+    L.orc_synth_p_dest_skewed.argtypes = [i64, i64, u64, i64, _f64p]
     L.orc_synth_datamatrix.argtypes = [i64, i64, u64, dbl, _f64p, _f64p]
     L.orc_createdatamatrix.argtypes = [vp, i64, i64, i64, vp]
     L.orc_centroids.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
@@ -199,9 +200,9 @@ def synth_p_drive(Z, T, table_seed):
     return out
 
 
-def synth_p_dest_dense(Z, T, table_seed):
+def synth_p_dest_dense(Z, T, table_seed, skew_q=0):
     out = np.zeros((Z, Z, T), dtype=np.float64, order="F")
-    lib().orc_synth_p_dest_dense(Z, T, table_seed, out)
+    _check(lib().orc_synth_p_dest_skewed(Z, T, table_seed, skew_q, out), "synth_p_dest")
     return out
 
 

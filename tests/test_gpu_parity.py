@@ -381,6 +381,42 @@ def test_sharded_sampler_stream_ordering(cpm, O):
         ss.close()
 
 
+def test_rccl_allreduce_on_the_sampler_stream(cpm):
+    """The device all-reduce really executes: a child process creates an RCCL process group (world size 1) before any GPU call,
+    then drives ShardedSampler's pipelined and blocking forms (tests/rccl_world1.py).  Its counts must equal a plain Sampler's.
+    (Several ranks cannot be run on the one-GPU box; the N = 2 logic runs over gloo in tests/test_host_logic.py.)"""
+    import hashlib
+    import json
+    import socket
+    import subprocess
+    import sys
+    Z, cpz, T = 512, 300, 24
+    C = Z * cpz
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_world1.py"), str(port), str(Z), str(cpz), hex(TABLE_SEED), hex(SIM_SEED)],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    want = {}
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        for seed in (SIM_SEED, SIM_SEED + 1):
+            r = s.resample(seed)
+            want[seed] = (hashlib.sha256(r["parking"].tobytes(order="F")).hexdigest(), hashlib.sha256(r["driving"].tobytes(order="F")).hexdigest())
+    assert len(out["steps"]) == 3
+    for st in out["steps"]:
+        assert st["cars_per_hour_ok"]
+        assert (st["parking"], st["driving"]) == want[SIM_SEED + (st["k"] & 1)], st["k"]
+    assert (out["sync"]["parking"], out["sync"]["driving"]) == want[SIM_SEED]
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_extreme_skew_everyone_to_one_zone(cpm, O, kernel):
     """Every row is a point mass on zone 3: after one hour the whole fleet sits in one bucket
@@ -722,6 +758,42 @@ def test_overflow_is_absorbed_by_growing_the_bucket_regions(cpm, O):
         from carparkingmaps_amd.distributed import split_counts
         pk, dr, _ = split_counts(counts, Z, T)
         assert np.array_equal(pk, ref["parking"]) and np.array_equal(dr, ref["driving"])
+
+
+def test_heavy_buckets_are_split_over_several_workgroups(cpm, O):
+    """Skewed destination popularity (the oracle's / the library's Zipf-Mandelbrot tables, bit-identical): a few zones hold many times
+    the mean.  The first grouped step walks such a bucket with one workgroup and reports its size; from then on the context launches
+    the heavy kernel with several blocks per zone (CPM_INFO_PARTS > 1).  Counts stay bit-exact on both sides of the switch, for the
+    IVP and for the resample, with and without travel times."""
+    Z, T, cpz, q = 192, 24, 1000, 4
+    C = Z * cpz
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED, skew_q=q)
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.9)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+    assert ref["parking"].max() > 2 * 4 * 256 + 1000         # a bucket well above twice the 4 x 256 slots of a sampler workgroup
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED, skew_q=q)
+        for (o, t) in [(1, 1), (Z, T), (77, 13)]:
+            assert np.array_equal(s.get_cdf_row(o, t), O.build_cdf(p_dest)[t - 1, o - 1]), (o, t)
+        s.set_datamatrix(dm, dist)
+        s.set_kernel(5)
+        s.init_states(C, cpz)
+        assert s.get_info(3) == 1
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        parts_after_ivp = s.get_info(3)
+        assert parts_after_ivp > 1                               # the IVP saw the heavy buckets
+        for k in range(3):
+            r = s.resample(SIM_SEED, travel=(k == 1))
+            assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), k
+            if k == 1:
+                assert r["sum_tt_q16"] == ref["sum_tt_q16"]
+            assert s.get_info(3) >= int(np.ceil(ref["parking"].max() / 1024)) - 1
+        # and from a fresh context whose very first step is already split (parts carried over by the IVP above are not needed)
+        s.init_states(C, cpz)
+        assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        r = s.resample(SIM_SEED)
+        assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"])
 
 
 def test_async_ivp_is_committed_on_the_tables_it_was_enqueued_with(cpm, O):

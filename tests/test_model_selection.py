@@ -66,6 +66,8 @@ def test_points_are_dealt_without_overlap():
     seen = sorted(i for r in range(8) for i in ms.points_of_rank(len(grid), r, 8))
     assert seen == list(range(256))
     assert max(len(ms.points_of_rank(256, r, 8)) for r in range(8)) == 32
+    assert sorted(i for r in range(3) for i in ms.points_of_rank(10, r, 3, order=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0])) == list(range(10))
+    assert ms.points_of_rank(10, 0, 3, order=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0]) == [9, 8, 7, 6]
 
 
 @pytest.mark.gpu
@@ -89,7 +91,8 @@ def test_grid_points_on_device_match_the_oracle(cpm, O):
     for i, pt in enumerate(grid):
         assert (halves[0][i] is None) != (halves[1][i] is None)
         got = full[i]
-        assert (halves[i % 2][i]["A_drive"], halves[i % 2][i]["driving_total"]) == (got["A_drive"], got["driving_total"])
+        half = halves[0][i] if halves[0][i] is not None else halves[1][i]
+        assert (half["A_drive"], half["driving_total"]) == (got["A_drive"], got["driving_total"])
         p_drive = O.createpdrive(dm, dist, Z, T, pt.p_min, pt.p_max, pt.e_drive)
         p_dest = O.createpdestin(dm, Z, T, pt.e_dest)
         ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, init, do_ivp=False, datamatrix=dm, dist=dist)
