@@ -323,7 +323,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
         c->status_pending = false;
         if (c->h_status[0] != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
-        c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));
+        c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));
     }
     HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
@@ -345,7 +345,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         if (rc == CPM_OK && c->h_status && !c->status_pending) {
             c->h_status[1] = 0;
             if (hipMemcpyAsync(c->h_status, d_counts + nwords - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                hipMemcpyAsync(c->h_status + 1, c->zg.maxn, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipMemcpyAsync(c->h_status + 1, c->zg.maxn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
                 hipEventRecord(c->status_ev, c->stream) == hipSuccess)
                 c->status_pending = true;
         }
@@ -395,7 +395,7 @@ int32_t ivp_grouped(cpm_ctx *c, uint64_t seed)
     if (rc != CPM_OK) return rc;
     c->h_ivp_status[1] = 0;
     HIP_TRY(hipMemcpyAsync(c->h_ivp_status, c->d_counts + 2 * c->T * c->Z + 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_ivp_status + 1, c->zg.maxn, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_ivp_status + 1, c->zg.maxn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return CPM_OK;
 }
 
@@ -406,7 +406,7 @@ int32_t finish_ivp(cpm_ctx *c)
     if (!c->ivp_pending) return CPM_OK;
     c->ivp_pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]));
+    c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]), static_cast<uint32_t>(c->h_ivp_status[1] >> 32));
     if (c->h_ivp_status[0] == 0) {
         std::swap(c->d_zone0, c->d_ztmp);
         HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
@@ -418,7 +418,7 @@ int32_t finish_ivp(cpm_ctx *c)
         int32_t rc = ivp_grouped(c, c->ivp_seed);
         if (rc != CPM_OK) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
-        c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]));
+        c->zg.set_parts(static_cast<uint32_t>(c->h_ivp_status[1]), static_cast<uint32_t>(c->h_ivp_status[1] >> 32));
         if (c->h_ivp_status[0] == 0) {
             std::swap(c->d_zone0, c->d_ztmp);
             HIP_TRY(cpm::grouped_commit_ivp(c->zg, c->stream));
@@ -1098,7 +1098,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
         int64_t status = 0;
         HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));  // (how the next grouped step is launched)
+        if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));  // (how the next grouped step is launched)
         c->status_pending = false;  // this step's status word is dealt with here: resample_enqueue must not grow the regions for it again
         // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
         while (status != 0 && rc == CPM_OK && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
@@ -1106,7 +1106,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
             if (rc != CPM_OK) break;
             HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]));
+            if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));
             c->status_pending = false;
         }
         if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout

@@ -208,11 +208,15 @@ struct GroupedArgs {
     uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
     uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
     unsigned long long *parking_t, *driving_t, *status;
-    uint32_t *maxn;           // largest bucket seen above 2 * CPT * BLOCK cars (atomicMax; the context sizes `parts` from it)
+    uint32_t *maxn;           // [2] what the context sizes the heavy launch from: the largest heavy bucket, the most heavy buckets in one hour
+    uint32_t *heavy_list;     // [hgrid] zones whose bucket this launch has handed to k_grouped_sample_heavy
+    uint32_t *nheavy_t;       // how many (this hour)
+    uint32_t hgrid;           // zones the heavy launch behind this one covers (its grid.x)
     int Z, Zp, Zq, G;
     uint32_t cap, scap, idbits, gshift, step;
-    uint32_t parts;           // 1: this launch walks whole buckets (overflow rounds of BLOCK cars).  > 1: it takes the first CPT * BLOCK
-                              // cars of every bucket and k_grouped_sample_heavy, launched behind it with parts - 1 blocks per zone, the rest
+    uint32_t parts;           // 1: this launch walks whole buckets (overflow rounds of BLOCK cars).  > 1: of a HEAVY bucket (more than
+                              // kHeavy * CPT * BLOCK cars) that gets a place in heavy_list it takes the first CPT * BLOCK cars only;
+                              // k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest
     CarIndex cars;
     uint64_t seed;
 };
@@ -353,6 +357,12 @@ __device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint
 #define CPM_STAGE 32
 #endif
 constexpr int kStage = CPM_STAGE;
+// A bucket is heavy above kHeavy x the slots of its sampler workgroup (4 x ~ the mean bucket: with the default bucket regions of
+// 4 x the mean no bucket gets there, so the heavy kernel is launched only in contexts whose regions have had to grow).  Lighter
+// overflow -- a quarter of the zones of the flat S4k tables hold a few cars more than CPT * BLOCK, the largest 2.5 x -- stays with
+// the overflow rounds of the first workgroup: handing it to a second launch cost more than it saved (profiles/round2_notes.md).
+constexpr uint32_t kHeavy = 4;
+constexpr int kHeavyCap = 4096;  // zones the heavy kernel can be handed in one hour (the rest stay with their first workgroup)
 #ifndef CPM_WPS
 #define CPM_WPS 6  // waves per SIMD the register allocator must leave room for (see profiles/round1_notes.md, round2_notes.md)
 #endif
@@ -379,7 +389,7 @@ template <int BLOCK, int CPT, int NQ, bool GROUPED>
 __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample(GroupedArgs a)
 {
     extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
-    __shared__ uint32_t s_ndrive, s_nstay;
+    __shared__ uint32_t s_ndrive, s_nstay, s_split;
     __shared__ uint32_t gb[kGroups];
     __shared__ uint32_t stage[GROUPED ? kGroups * kStage : 1];
     const int Z = a.Z;
@@ -404,16 +414,27 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
     const uint32_t n_all = min(n_raw, cap);
-    // a bucket beyond CPT * BLOCK cars: walked here BLOCK cars at a time (parts == 1), or left to the heavy kernel (parts > 1)
-    const uint32_t n = (a.parts > 1) ? min(n_all, static_cast<uint32_t>(CPT * BLOCK)) : n_all;
+    // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
+    // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
+    const bool heavy = n_all > kHeavy * CPT * BLOCK;
     if (tid == 0) {
         a.parking_t[z] = n_all;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         s_ndrive = 0;
         s_nstay = 0;
-        if (n_all > 2u * CPT * BLOCK) atomicMax(a.maxn, n_all);  // (never on flat tables: a bucket twice the slots of its workgroup)
+        uint32_t split = 0;
+        if (heavy) {
+            atomicMax(&a.maxn[0], n_all);
+            const uint32_t idx = atomicAdd(a.nheavy_t, 1u);
+            atomicMax(&a.maxn[1], idx + 1u);
+            if (GROUPED && a.parts > 1 && idx < a.hgrid) {
+                a.heavy_list[idx] = static_cast<uint32_t>(z);
+                split = 1;
+            }
+        }
+        s_split = split;
     }
     if (tid < kGroups) gb[tid] = 0;
-    if (n == 0) {  // driving_t[z] stays 0 (zeroed by the caller)
+    if (n_all == 0) {  // driving_t[z] stays 0 (zeroed by the caller)
         if (GROUPED) {
             if (tid == 0) a.cnt_next[z] = 0;
             if (tid < kGroups) a.cntg[static_cast<size_t>(z) * kGroups + tid] = 0;
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     uint32_t dest[CPT], clo[CPT], khi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n;
+        valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n_all;
         long long kb;
         car_draw_words(a.seed, a.cars.global(id[c]), a.step, kb, clo[c], khi[c]);
         drive[c] = valid[c] & (kb <= thr);       // u <= p_drive[origin,t] (src/resampling.jl:15) in integers
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     // barrier makes every wave's pieces visible to every wave.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const uint32_t n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
     const uint32_t hi_last = hi[Z - 1];
@@ -551,11 +573,11 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     }
 }
 
-// The rest of the buckets that hold more than CPT * BLOCK cars (real Uber Movement tables are peaky: a central zone can hold tens of
-// times the mean, and one workgroup walking it BLOCK cars at a time is the tail of the whole launch).  Launched behind
-// k_grouped_sample when the context has seen such buckets (GroupedArgs::parts > 1), with parts - 1 blocks per zone: block (z, q)
-// takes the chunks q, q + (parts - 1), ... of CPT * BLOCK cars behind the first one and exits at once when there is none (nearly
-// all of them do).  It shares the zone's outputs with the first workgroup and its sibling blocks, which have already written theirs
+// The rest of the HEAVY buckets (real Uber Movement tables are peaky: a central zone can hold tens of times the mean, and one
+// workgroup walking it BLOCK cars at a time is the tail of the whole launch).  Launched behind
+// k_grouped_sample when the context has seen such buckets (GroupedArgs::parts > 1), with parts - 1 blocks for each of the hgrid
+// zones the sampler may list in heavy_list: block (i, q) takes the chunks q, q + (parts - 1), ... of CPT * BLOCK cars behind the first
+// one of the i-th listed zone.  It shares the zone's outputs with the first workgroup and its sibling blocks, which have already written theirs
 // or are writing them now: stayers take their slots in next hour's bucket with one global ticket per wave (cnt_next[z], which the
 // placing kernel goes on adding to), drivers are ranked per chunk in LDS and reserve their range of the zone's runs with one
 // global atomic per (chunk, destination group) on the run length, driving counts are added.  Order inside buckets and runs is
@@ -566,7 +588,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     extern __shared__ uint32_t pack[];
     __shared__ uint32_t gb[kGroups], gbase[kGroups];
     const int Z = a.Z;
-    const int z = blockIdx.x;
+    if (blockIdx.x >= min(*a.nheavy_t, a.hgrid)) return;  // (the list of this hour is shorter than the grid)
+    const int z = static_cast<int>(a.heavy_list[blockIdx.x]);
     const uint32_t q = blockIdx.y, nq = a.parts - 1u;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr uint32_t L = CPT * BLOCK;
@@ -695,6 +718,10 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
     // delta: (this block's first position inside the zone's bucket) - (the zone's first index in the sorted list)
     __shared__ uint32_t bins[kMaxZonesPerGroup], tbins[kMaxZonesPerGroup], delta[kMaxZonesPerGroup];
     __shared__ uint32_t wsum[kPlaceBlock / 64], s_total;
+    // runs longer than the 16 * KDEEP entries their lanes hold (skewed tables: a heavy origin zone, a popular destination group): the
+    // entries beyond are dealt over ALL threads of the block -- lstart[r] = first index of run r's surplus in that flat list
+    constexpr int kRuns = KRUNS * kPlaceSeg;
+    __shared__ uint32_t lstart[kRuns + 1], s_any_long;
     extern __shared__ uint32_t sorted_ids[];                                  // [kSlots] ids in destination order
     uint16_t *sorted_zone = reinterpret_cast<uint16_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -709,20 +736,24 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         bins[k] = 0;
         tbins[k] = 0;
     }
+    if (tid == 0) s_any_long = 0;
     if (zs0 >= zs1) return;  // (uniform per block)
     uint32_t c[KRUNS], v[KRUNS][KDEEP], r[KRUNS][KDEEP];
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
-        const int zs = zs0 + sub + k * kPlaceSeg;
-        const int zc = min(zs, zs1 - 1);
+    for (int k = 0; k < KRUNS; ++k) {  // (nothing here depends on a loaded value: all 12 requests leave before the first wait)
+        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
-        c[k] = min(cntg[run], scap);  // (beyond scap only when the heavy kernel flagged an overflow: the step is repeated)
-        if (zs >= zs1) c[k] = 0;
+        c[k] = cntg[run];
 #pragma unroll
         for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
     }
     __syncthreads();
     CPM_PSTAMP(1);
+#pragma unroll
+    for (int k = 0; k < KRUNS; ++k) {
+        c[k] = min(c[k], scap);  // (beyond scap only when the heavy kernel flagged an overflow: the step is repeated)
+        if (zs0 + sub + k * kPlaceSeg >= zs1) c[k] = 0;
+    }
     // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
@@ -732,24 +763,55 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
             if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
         }
     }
+    if (l16 == 0) {
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
-        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
-        const size_t run = static_cast<size_t>(zc) * kGroups + g;
-        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) atomicAdd(&tbins[D[run * scap + i] >> idbits], 1u);
+        for (int k = 0; k < KRUNS; ++k) {
+            const uint32_t surplus = c[k] > 16u * KDEEP ? c[k] - 16u * KDEEP : 0u;
+            lstart[sub + k * kPlaceSeg] = surplus;
+            if (surplus) s_any_long = 1u;
+        }
     }
     CPM_PSTAMP(2);
     __syncthreads();
     CPM_PSTAMP(3);
-    // ticket (this block's range inside each bucket of the group) and the zones' offsets in the sorted list (block scan of bins)
-    {
-        const bool zone = tid < nzl;
-        const uint32_t cr = zone ? bins[tid] : 0u, ct = zone ? tbins[tid] : 0u;
-        uint32_t base = 0;
-        if (cr + ct) {
-            base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
-            if (base + cr + ct > cap) atomicOr(status, 2ull);
+    // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
+    auto surplus_entry = [&](uint32_t e) -> uint32_t {
+        int r = 0;
+#pragma unroll
+        for (int step = kRuns / 2; step > 0; step >>= 1)
+            if (lstart[r + step] <= e) r += step;
+        const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + (r % kPlaceSeg) + (r / kPlaceSeg) * kPlaceSeg = zs0 + r)
+        return D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - lstart[r])];
+    };
+    const bool any_long = s_any_long != 0;  // (block-uniform)
+    uint32_t ltotal = 0;
+    if (any_long) {
+        // exclusive scan of the surplus lengths (kRuns <= kPlaceBlock values, one per thread), then the histogram of the surplus
+        const uint32_t len = tid < kRuns ? lstart[tid] : 0u;
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (tid < kRuns) lstart[tid] = before + incl - len;
+        if (tid == kRuns - 1) lstart[kRuns] = before + incl;
+        __syncthreads();
+        ltotal = lstart[kRuns];
+        for (uint32_t e = tid; e < ltotal; e += kPlaceBlock) atomicAdd(&tbins[surplus_entry(e) >> idbits], 1u);
+        __syncthreads();
+    }
+    // The ticket (this block's range inside each bucket of the group) is requested now and needed only when the sorted list is
+    // written out: its round trip runs under the block scan of the histogram (the zones' offsets in the sorted list) and the sort.
+    const bool zone = tid < nzl;
+    const uint32_t cr = zone ? bins[tid] : 0u, ct = zone ? tbins[tid] : 0u;
+    uint32_t base = 0;
+    if (cr + ct) base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
+    uint32_t first;
+    {
         uint32_t incl = cr;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(incl, o, 64);
@@ -759,18 +821,14 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         __syncthreads();
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wsum[w];  // (16 waves)
-        const uint32_t first = before + incl - cr;
-        if (zone) {
-            bins[tid] = first;
-            tbins[tid] = base + cr;
-            delta[tid] = base - first;  // (wraps; only base - first + index is used)
-        }
+        first = before + incl - cr;
+        if (zone) bins[tid] = first;
         if (tid == kPlaceBlock - 1) s_total = before + incl;
     }
     CPM_PSTAMP(4);
     __syncthreads();
     CPM_PSTAMP(5);
-    // pass B: the entries held in registers go to their place in the sorted list ...
+    // pass B: the entries held in registers go to their place in the sorted list
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
 #pragma unroll
@@ -782,25 +840,25 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
                 sorted_zone[li] = static_cast<uint16_t>(dl);
             }
     }
-    // ... the entries beyond a run's first 16 * KDEEP straight to their buckets (rare on flat tables) ...
-#pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
-        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
-        const size_t run = static_cast<size_t>(zc) * kGroups + g;
-        for (uint32_t i = l16 + 16 * KDEEP; i < c[k]; i += 16) {
-            const uint32_t w = D[run * scap + i];
-            const uint32_t dl = w >> idbits;
-            const uint32_t p = atomicAdd(&tbins[dl], 1u);
-            if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
-        }
+    if (zone) {  // (first use of the ticket)
+        if (base + cr + ct > cap) atomicOr(status, 2ull);
+        tbins[tid] = base + cr;
+        delta[tid] = base - first;  // (wraps; only base - first + index is used)
     }
     __syncthreads();
-    // ... and the sorted list out: consecutive lanes, consecutive slots of one bucket
+    // the sorted list out: consecutive lanes, consecutive slots of one bucket ...
     const uint32_t total = s_total;
     for (uint32_t i = tid; i < total; i += kPlaceBlock) {
         const uint32_t dl = sorted_zone[i];
         const uint32_t p = delta[dl] + i;
         if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = sorted_ids[i];
+    }
+    // ... and the surplus of the long runs straight to their buckets
+    for (uint32_t e = tid; e < ltotal; e += kPlaceBlock) {
+        const uint32_t w = surplus_entry(e);
+        const uint32_t dl = w >> idbits;
+        const uint32_t p = atomicAdd(&tbins[dl], 1u);
+        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
     }
     CPM_PSTAMP(6);
 }
@@ -1010,7 +1068,7 @@ inline void grouped_launch_heavy_nq(const GroupedArgs &a, size_t lds, hipStream_
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(a.Z, a.parts - 1), dim3(kSampleBlock), lds, stream, a);
+    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(a.hgrid, a.parts - 1), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <int CPT>
@@ -1029,7 +1087,7 @@ inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2
 
 inline void grouped_launch_heavy(const GroupedArgs &a, int64_t mean, hipStream_t stream)
 {
-    if (a.parts <= 1) return;
+    if (a.parts <= 1 || a.hgrid == 0) return;
     switch (grouped_cpt(mean)) {
     case 1: grouped_launch_heavy_c<1>(a, stream); break;
     case 2: grouped_launch_heavy_c<2>(a, stream); break;
@@ -1139,20 +1197,23 @@ struct GroupedWork {
     uint32_t *Dq = nullptr;                                      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;                                    // [Z][kGroups] run lengths
     unsigned long long *tt_part = nullptr;                       // [kTravelParts] partial travel-time sums, kept zero between resamples
-    uint32_t *maxn = nullptr;                                    // [1] largest heavy bucket (> 2 x the sampler workgroup's slots) of the current run
-    int parts = 1;                                               // workgroups per zone of the sampler: 1 + blocks of the heavy kernel (set_parts)
+    uint32_t *maxn = nullptr;                                    // [2] of the current run: largest heavy bucket (> kHeavy x the sampler workgroup's slots), most heavy buckets in one hour
+    uint32_t *heavy_list = nullptr, *nheavy = nullptr;           // [kHeavyCap] zones handed to the heavy kernel this hour; [T+1] how many, per hour
+    int parts = 1;                                               // workgroups per heavy zone: 1 + blocks of the heavy kernel (set_parts)
+    int hgrid = 0;                                               // zones the heavy launch covers
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
 
     // what the last run saw -> how the next one is launched: enough workgroups per zone for the largest bucket, at most 32
-    void set_parts(uint32_t largest_heavy_bucket)
+    void set_parts(uint32_t largest_heavy_bucket, uint32_t most_heavy_buckets)
     {
         const int64_t slots = static_cast<int64_t>(grouped_cpt((n + Z - 1) / std::max(Z, 1))) * kSampleBlock;
         parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(32, (largest_heavy_bucket + slots - 1) / slots)));
+        hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 8)) : 0;
     }
 
     void release()
     {
-        for (uint32_t **p : {&ids0, &idsA, &idsB, &cnt0, &cnt, &Dq, &cntg}) {
+        for (uint32_t **p : {&ids0, &idsA, &idsB, &cnt0, &cnt, &Dq, &cntg, &heavy_list, &nheavy}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -1190,9 +1251,11 @@ struct GroupedWork {
         alloc(&cnt, static_cast<size_t>(T + 1) * Z);
         alloc(&Dq, static_cast<size_t>(Z) * kGroups * scap);
         alloc(&cntg, static_cast<size_t>(Z) * kGroups);
+        alloc(&heavy_list, kHeavyCap);
+        alloc(&nheavy, static_cast<size_t>(T) + 1);
         if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
-        if (e == hipSuccess) e = hipMalloc(&maxn, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&maxn, 2 * sizeof(uint32_t));
         if (e != hipSuccess) release();
         return e;
     }
@@ -1236,7 +1299,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     unsigned long long *status = tt_sum + 1;
     e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(w.maxn, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w.maxn, 0, 2 * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * (static_cast<size_t>(T) + 1), stream);
     if (e != hipSuccess) return hip_fail(e, "memset counters");
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
@@ -1273,7 +1337,10 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.status = status;
         a.maxn = w.maxn;
+        a.heavy_list = w.heavy_list;
+        a.nheavy_t = w.nheavy + t;
         a.parts = grouped ? static_cast<uint32_t>(w.parts) : 1u;
+        a.hgrid = grouped ? static_cast<uint32_t>(w.hgrid) : 0u;
         a.Z = Z;
         a.Zp = tb.Zp;
         a.Zq = tb.Zq;

@@ -2,7 +2,12 @@
 // src/createpdestin.jl).  Input: datamatrix[o + Z*(d + Z*(t + T*k))] and dist[o + Z*d] in the
 // reference's column-major layout; every kernel puts the origin on the lane so that all
 // HBM accesses are coalesced (the reference walks the same arrays at stride Z or Z*Z).
-// Sums run left to right over the destination in f64, like the reference's loops.
+// Sums run left to right over the destination in f64: this build's pinned order (the oracle's too).  createpdrive's mean is the same
+// explicit sequential loop in the reference (src/createpdrive.jl:14-18); createpdestin's normaliser is NOT: the reference calls
+// sum(p_dest[i, :, t]) (src/createpdestin.jl:33), Julia's pairwise sum, which can differ from the sequential sum by an ulp.  Julia
+// parity of these tables is UNPINNED: nothing reference-held covers them, and x^0.5 is Julia's pow there, evaluated here as sqrt;
+// other float exponents go through the device pow (a few ulp from glibc's / Julia's).  Statistically irrelevant; said so that no
+// comment claims more than the tests show (device == oracle, bit for bit or to 4e-16).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,7 +31,7 @@ __global__ void k_pdrive_mean(const double *__restrict__ dm, const double *__res
     const double *dst = dist + i;
     double s = 0.0;
     long long counter = 0;
-    // The sum runs left to right (the reference's order) but the loads do not depend on it: kTabBatch of them are requested
+    // The sum runs left to right (src/createpdrive.jl:14-18 is the same explicit loop) but the loads do not depend on it: kTabBatch of them are requested
     // together, so that a lane has kTabBatch x 2 loads in flight instead of one round trip per destination.
     int j = 0;
     for (; j + kTabBatch <= Z; j += kTabBatch) {
@@ -126,7 +131,7 @@ __global__ void k_pdest_weights(const double *__restrict__ dm, double *__restric
     }
 }
 
-// normalise per (i,t): nf = sum_j p[i,j,t] left to right; divide if nf > 0   (createpdestin.jl:31-46)
+// normalise per (i,t): nf = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33); divide if nf > 0 (:38-46)
 __global__ void k_pdest_normalise(double *__restrict__ p, int Z)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -129,3 +129,14 @@ def test_c_harness_call_sequence_equals_the_ctypes_path(cpm, tmp_path):
     assert int(got["parking"], 16) == _fnv(r["parking"].ravel(order="F")) and int(got["driving"], 16) == _fnv(r["driving"].ravel(order="F"))
     assert int(got["tt"]) == 0 and int(got["compat_counts_equal"]) == 1 and int(got["hour24_cars"]) == C
     assert int(got["state"], 16) == _fnv(r2["state"].ravel(order="F")) and int(got["trans"], 16) == _fnv(r2["trans"].ravel(order="F"))
+
+
+def test_every_lds_dma_sampler_waits_for_its_pack_before_the_barrier(cpm):
+    """`make asm-check`: in the device assembly of every instantiation of the kernels that stage a row pack by LDS-DMA there is an
+    s_waitcnt vmcnt(0) between the last global_load_lds and the first s_barrier behind it (tools/check_sampler_asm.py)."""
+    import subprocess
+    from carparkingmaps_amd import _lib
+    out = subprocess.run(["make", "-C", os.path.dirname(_lib.LIB_PATH), "asm-check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    n, bad = map(int, re.search(r"(\d+) kernels with LDS-DMA staging checked, (\d+) without", out.stdout).groups())
+    assert n >= 60 and bad == 0

@@ -61,6 +61,18 @@ for k in sorted(set(fetch) | set(write)):
     total = 2 * fa * 1024 + wa * 1024
     traffic[k] = {"launches": len(f), "fetch_kib": fa, "write_kib": wa, "hbm_bytes_per_launch": total, "l2_hit_rate": hr}
     lines.append(f"| `{k[:60]}` | {len(f)} | {fa:.0f} | {wa:.0f} | {total:.3e} | {hr:.3f} |")
+sweep = one("sweep/**/*_kernel_stats.csv")
+if sweep:
+    shutil.copy(sweep, os.path.join(dst, f"{name}_sweep_kernel_stats.csv"))
+    lines += ["", "## Model-selection sweep (tools/sweep_bench.py --points 16: Z = 2,357 x 1,000 cars/zone, travel times on, table rebuilds per point)", "",
+              "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+    for r in list(csv.DictReader(open(sweep)))[:14]:
+        lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['Percentage']):.1f} |")
+    log = os.path.join(src, "sweep.log")
+    if os.path.exists(log):
+        lines += [""] + ["    " + l.rstrip() for l in open(log) if "grid points" in l or "IVP" in l]
+head = os.popen(f"git -C {root} rev-parse --short HEAD 2>/dev/null").read().strip()
+lines.insert(1, f"(tree at {head or 'unknown commit'} + working changes; collected by tools/collect_profiles.sh)")
 open(os.path.join(dst, f"{name}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(dst, f"{name}_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
