@@ -191,10 +191,10 @@ def main():
         barrier()
     if kernel_used == 0:
         kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
-    # hipEvents on the launch stream around every 7th hourly sampler launch of the timed region (7 is
+    # hipEvents on the launch stream around every 25th hourly sampler launch of the timed region (25 is
     # coprime to 24, so every hour of the day is sampled).  Bracketing every launch was measured to put
-    # two ~5 us bubbles around each of them: 12 % of the step.
-    s.set_profile(True, stride=7, kernel=0)
+    # two ~5 us bubbles around each of them: 12 % of the step; every 25th costs the step 0.5 %.
+    s.set_profile(True, stride=25, kernel=0)
     barrier()
     t0 = time.perf_counter()
     counts = run_steps(args.steps)

@@ -877,8 +877,10 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
                        static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);
     hipError_t e = hipGetLastError();
     int32_t rc_thr = (e == hipSuccess) ? update_thr(c) : CPM_OK;
-    if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && out) {  // (without a host copy to wait for the call returns as soon as the kernels are enqueued: everything that
+        e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);  // uses the table follows on the same stream)
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_drive: %s", hipGetErrorString(e));
     if (rc_thr != CPM_OK) return rc_thr;
     c->have_pdrive = true;

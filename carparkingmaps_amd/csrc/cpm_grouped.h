@@ -39,6 +39,14 @@ constexpr int kMaxZonesPerGroup = 1024;  // LDS bins of the place kernel
 constexpr uint32_t kHiMax = 0xFFFFFFFFu;
 constexpr int kMaxCapMult = 64;
 
+// destination groups of 2^gshift consecutive zones, at most kGroups of them
+inline uint32_t grouped_gshift_of(int Z)
+{
+    uint32_t s = 0;
+    while ((static_cast<int64_t>(kGroups) << s) < Z) ++s;
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------------ row packs
 __host__ __device__ inline int pack_guide_bits(int Z)
 {
@@ -698,20 +706,22 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
 // one L2: all writes to a bucket merge there; speed only, never correctness).  Block (g, j) takes the group-g runs of the origin
 // zones [j*zps, (j+1)*zps): 16 lanes per run, KDEEP entries per lane.  Run lengths and run contents sit at addresses known up
 // front, so they are requested together.
-constexpr int kPlaceBlock = 1024;
-constexpr int kPlaceSeg = kPlaceBlock / 16;
+// Threads per block: 512 (128 origin zones per block, four blocks per CU; measured at S4k against 1024 x two per CU: 11.4 us against
+// 12.4 -- the kernel is a chain of round trips and barriers, and four shorter chains per CU interleave better than two; 256: 13.2),
+// 1024 when a destination group holds more than 512 zones (one thread per zone takes the ticket and the scan).
 
 // What bounds this kernel is the number of cache lines a store instruction touches (in-kernel stamps, profiles/round2_notes.md:
 // with every lane storing its own entry -- 64 buckets per wave-instruction -- issuing the stores took a third of a block's life).
 // So the block's entries are first sorted by destination zone in LDS (their rank inside the block is known from pass A, the
 // zones' offsets from a scan of the block's histogram) and then written out in that order: consecutive lanes write consecutive
 // slots of one bucket.
-template <int KRUNS, int KDEEP>
-__global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
+template <int PB, int KRUNS, int KDEEP>
+__global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
                                                                int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
                                                                uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
                                                                unsigned long long *status)
 {
+    constexpr int kPlaceBlock = PB, kPlaceSeg = PB / 16;
     constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;  // entries a block can hold in registers
     // bins : per destination zone: entries held in registers (pass A), then their first index in the sorted list
     // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those inside the bucket
@@ -721,6 +731,7 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
     // runs longer than the 16 * KDEEP entries their lanes hold (skewed tables: a heavy origin zone, a popular destination group): the
     // entries beyond are dealt over ALL threads of the block -- lstart[r] = first index of run r's surplus in that flat list
     constexpr int kRuns = KRUNS * kPlaceSeg;
+    constexpr int kSurplusBatch = 4;
     __shared__ uint32_t lstart[kRuns + 1], s_any_long;
     extern __shared__ uint32_t sorted_ids[];                                  // [kSlots] ids in destination order
     uint16_t *sorted_zone = reinterpret_cast<uint16_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
@@ -801,7 +812,14 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         if (tid == kRuns - 1) lstart[kRuns] = before + incl;
         __syncthreads();
         ltotal = lstart[kRuns];
-        for (uint32_t e = tid; e < ltotal; e += kPlaceBlock) atomicAdd(&tbins[surplus_entry(e) >> idbits], 1u);
+        for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {  // (a thread's kSurplusBatch loads are in flight together)
+            uint32_t w[kSurplusBatch];
+#pragma unroll
+            for (int u = 0; u < kSurplusBatch; ++u) w[u] = (e0 + u * kPlaceBlock < ltotal) ? surplus_entry(e0 + u * kPlaceBlock) : 0u;
+#pragma unroll
+            for (int u = 0; u < kSurplusBatch; ++u)
+                if (e0 + u * kPlaceBlock < ltotal) atomicAdd(&tbins[w[u] >> idbits], 1u);
+        }
         __syncthreads();
     }
     // The ticket (this block's range inside each bucket of the group) is requested now and needed only when the sorted list is
@@ -854,45 +872,72 @@ __global__ __launch_bounds__(kPlaceBlock) void k_grouped_place(const uint32_t *_
         if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = sorted_ids[i];
     }
     // ... and the surplus of the long runs straight to their buckets
-    for (uint32_t e = tid; e < ltotal; e += kPlaceBlock) {
-        const uint32_t w = surplus_entry(e);
-        const uint32_t dl = w >> idbits;
-        const uint32_t p = atomicAdd(&tbins[dl], 1u);
-        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w & idmask;
+    for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {
+        uint32_t w[kSurplusBatch];
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u) w[u] = (e0 + u * kPlaceBlock < ltotal) ? surplus_entry(e0 + u * kPlaceBlock) : 0u;
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u)
+            if (e0 + u * kPlaceBlock < ltotal) {
+                const uint32_t dl = w[u] >> idbits;
+                const uint32_t p = atomicAdd(&tbins[dl], 1u);
+                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w[u] & idmask;
+            }
     }
     CPM_PSTAMP(6);
 }
 
-// Blocks of the place kernel per destination group: at most 256 origin zones per block (one run per 16 lanes, four runs per
-// thread) from 1024 zones on -- measured at S4k: 8 blocks 16.9 us, 16 blocks 15.3 us.
-inline int place_bpg(int Z)
+// Geometry of a placing launch: threads per block, runs per 16-lane group (KRUNS = 4 or 8), blocks per destination group
+struct PlaceShape {
+    int pb, kruns, bpg;
+};
+inline PlaceShape place_shape(int Z)
 {
-    if (Z < 1024) return 8;
-    int b = 16;
-    while (b < 64 && (Z + b - 1) / b > 256) b *= 2;
-    return b;
+    const int zpg = 1 << grouped_gshift_of(Z);
+    PlaceShape p;
+    p.pb = zpg <= 512 ? 512 : 1024;
+    const int seg = p.pb / 16;
+    p.bpg = Z < 1024 ? 8 : 16;
+    while (p.bpg < 128 && (Z + p.bpg - 1) / p.bpg > 4 * seg) p.bpg *= 2;
+    p.kruns = (Z + p.bpg - 1) / p.bpg <= 4 * seg ? 4 : 8;
+    return p;
+}
+inline bool place_shape_fits(int Z)
+{
+    const PlaceShape p = place_shape(Z);
+    return (Z + p.bpg - 1) / p.bpg <= 8 * (p.pb / 16);
+}
+
+template <int PB, int KRUNS>
+inline void grouped_launch_place_t(hipStream_t stream, int bpg, const uint32_t *D, const uint32_t *cntg, int zpg, int Z, uint32_t cap, uint32_t scap,
+                                   uint32_t idbits, uint32_t *cnt_next, uint32_t *ids_next, unsigned long long *status)
+{
+    const int zps = (Z + bpg - 1) / bpg;
+    const size_t lds = static_cast<size_t>(6) * KRUNS * 2 * PB;  // sorted ids (4 B) + their zones (2 B) per slot
+    if (lds > 48 * 1024) {  // LDS opt-in, once per device
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_place<PB, KRUNS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds));
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_grouped_place<PB, KRUNS, 2>), dim3(kGroups * bpg), dim3(PB), lds, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
+                       ids_next, status);
 }
 
 inline void grouped_launch_place(hipStream_t stream, const uint32_t *D, const uint32_t *cntg, int zpg, int Z, uint32_t cap, uint32_t scap,
                                  uint32_t idbits, uint32_t *cnt_next, uint32_t *ids_next, unsigned long long *status)
 {
-    const int bpg = place_bpg(Z);
-    const int zps = (Z + bpg - 1) / bpg;
-    const dim3 grid(kGroups * bpg), block(kPlaceBlock);
-    static bool attr_done[64] = {};  // LDS opt-in for the larger form, once per device
-    if (zps <= 4 * kPlaceSeg) {
-        hipLaunchKernelGGL((k_grouped_place<4, 2>), grid, block, 6 * 4 * 2 * kPlaceBlock, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
-                           ids_next, status);
-    } else {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_place<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8 * 2 * kPlaceBlock);
-            if (dev >= 0 && dev < 64) attr_done[dev] = true;
-        }
-        hipLaunchKernelGGL((k_grouped_place<8, 2>), grid, block, 6 * 8 * 2 * kPlaceBlock, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
-                           ids_next, status);
-    }
+    const PlaceShape p = place_shape(Z);
+#define CPM_PLACE_ARGS stream, p.bpg, D, cntg, zpg, Z, cap, scap, idbits, cnt_next, ids_next, status
+    if (p.pb == 512 && p.kruns == 4) grouped_launch_place_t<512, 4>(CPM_PLACE_ARGS);
+    else if (p.pb == 512) grouped_launch_place_t<512, 8>(CPM_PLACE_ARGS);
+    else if (p.kruns == 4) grouped_launch_place_t<1024, 4>(CPM_PLACE_ARGS);
+    else grouped_launch_place_t<1024, 8>(CPM_PLACE_ARGS);
+#undef CPM_PLACE_ARGS
 }
 
 // ------------------------------------------------------------------------------------------------ travel times
@@ -929,18 +974,24 @@ __global__ __launch_bounds__(kTtTile * 8) void k_build_travel_table(const double
 }
 
 struct TravelArgs {
-    const double2 *tt_t;          // [Z][Z] (mean, std) of this hour, origin-major
+    const double2 *tt;            // [T][Z][Z] (mean, std), origin-major
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
-    int T, t, gshift;
-    uint32_t step;
+    size_t d_stride, c_stride;    // words between the runs / run lengths of consecutive hours (one launch for all hours), or 0
+    int t0, gshift;               // hour of blockIdx.y = 0
+    uint32_t step0;               // its Philox step
     CarIndex cars;
     uint64_t seed;
 };
 
-// one 256-thread block per origin zone
+// one 256-thread block per (origin zone, hour).  When the runs of all hours of a resample are kept (GroupedWork::history) ONE launch
+// at the end serves them all: 24 x fewer launches and a grid 24 x as deep (at Z = 2,357 an hourly grid is 1.15 rounds of blocks).
 __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
                                                         uint32_t idbits, TravelArgs tr)
 {
+    const int hour = tr.t0 + static_cast<int>(blockIdx.y);
+    const uint32_t step = tr.step0 + blockIdx.y;
+    D += tr.d_stride * blockIdx.y;
+    cntg += tr.c_stride * blockIdx.y;
     // The zone's drivers are dealt evenly over the threads whatever the run lengths are (popular destination groups
     // hold most of them): driver i of the zone sits in run g with prefix[g] <= i < prefix[g+1].
     __shared__ uint32_t prefix[kGroups + 1];
@@ -967,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
     // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
     constexpr int kTravelBatch = 4;
-    const double2 *tt_row = tr.tt_t + static_cast<size_t>(z) * Z;
+    const double2 *tt_row = tr.tt + (static_cast<size_t>(hour) * Z + z) * Z;
     for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
         uint32_t w[kTravelBatch], dest[kTravelBatch];
         bool live[kTravelBatch];
@@ -998,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
                 tt += q16(300.0);
             } else {
                 const double s1 = (sd[u] == 0) ? 0.1 * mean[u] : sd[u];  // :65-67
-                tt += q16(truncnormal_pm10(tr.seed, tr.cars.global(w[u] & idmask), tr.step, 1, mean[u], s1));
+                tt += q16(truncnormal_pm10(tr.seed, tr.cars.global(w[u] & idmask), step, 1, mean[u], s1));
             }
         }
     }
@@ -1007,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     for (int o = 32; o > 0; o >>= 1) tt += __shfl_down(tt, o, 64);
     if (lane == 0 && tt) atomicAdd(&s_tt, static_cast<unsigned long long>(tt));
     __syncthreads();
-    if (tid == 0 && s_tt) atomicAdd(&tr.tt_part[z % kTravelParts], s_tt);
+    if (tid == 0 && s_tt) atomicAdd(&tr.tt_part[(z + 31 * blockIdx.y) % kTravelParts], s_tt);
 }
 
 __global__ __launch_bounds__(256) void k_grouped_travel_finish(unsigned long long *__restrict__ tt_part, unsigned long long *__restrict__ tt_sum)
@@ -1156,13 +1207,7 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
 // ------------------------------------------------------------------------------------------------ workspace and driver
 // run capacity: a quarter of a bucket region (= the mean bucket size at cap_mult 4), >= 64, whole 128-B lines
 inline uint32_t grouped_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
-// groups of 2^gshift consecutive zones, at most kGroups of them
-inline uint32_t grouped_gshift(int Z)
-{
-    uint32_t s = 0;
-    while ((static_cast<int64_t>(kGroups) << s) < Z) ++s;
-    return s;
-}
+inline uint32_t grouped_gshift(int Z) { return grouped_gshift_of(Z); }
 // packed driver = id | (dest mod 2^gshift) << idbits
 inline uint32_t grouped_idbits(int Z) { return 32u - std::max(1u, grouped_gshift(Z)); }
 inline uint32_t grouped_cap(int64_t n, int Z, int cap_mult)
@@ -1178,7 +1223,7 @@ inline bool grouped_path_fits(int64_t n, int Z, int cap_mult = 4)
     if (!pack_row_fits(Z) || n < 1 || n >= (int64_t(1) << 30)) return false;
     const uint32_t cap = grouped_cap(n, Z, cap_mult);
     if (n > (int64_t(1) << grouped_idbits(Z)) || (1 << grouped_gshift(Z)) > kMaxZonesPerGroup) return false;
-    if ((Z + place_bpg(Z) - 1) / place_bpg(Z) > 8 * kPlaceSeg) return false;
+    if (!place_shape_fits(Z)) return false;
     const int64_t bytes = static_cast<int64_t>(Z) * cap * 4 * 3 + static_cast<int64_t>(Z) * kGroups * grouped_scap(cap) * 4;
     return bytes <= (int64_t(cap_mult <= 4 ? 24 : 80) << 30);
 }
@@ -1199,6 +1244,7 @@ struct GroupedWork {
     unsigned long long *tt_part = nullptr;                       // [kTravelParts] partial travel-time sums, kept zero between resamples
     uint32_t *maxn = nullptr;                                    // [2] of the current run: largest heavy bucket (> kHeavy x the sampler workgroup's slots), most heavy buckets in one hour
     uint32_t *heavy_list = nullptr, *nheavy = nullptr;           // [kHeavyCap] zones handed to the heavy kernel this hour; [T+1] how many, per hour
+    int run_hours = 1;                                           // copies of Dq / cntg: 1, or T when the runs of every hour of a resample are kept (ensure_history)
     int parts = 1;                                               // workgroups per heavy zone: 1 + blocks of the heavy kernel (set_parts)
     int hgrid = 0;                                               // zones the heavy launch covers
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
@@ -1209,6 +1255,27 @@ struct GroupedWork {
         const int64_t slots = static_cast<int64_t>(grouped_cpt((n + Z - 1) / std::max(Z, 1))) * kSampleBlock;
         parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(32, (largest_heavy_bucket + slots - 1) / slots)));
         hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 8)) : 0;
+    }
+
+    size_t run_words() const { return static_cast<size_t>(Z) * kGroups * scap; }
+    size_t len_words() const { return static_cast<size_t>(Z) * kGroups; }
+    // Room for the runs of all T hours (travel times in one launch at the end of a resample), when they fit 24 GiB; else one copy.
+    bool ensure_history()
+    {
+        if (run_hours == T) return true;
+        if (run_words() * 4 * static_cast<size_t>(T) > (size_t(24) << 30)) return false;
+        uint32_t *d = nullptr, *c = nullptr;
+        if (hipMalloc(&d, sizeof(uint32_t) * run_words() * T) != hipSuccess) return false;
+        if (hipMalloc(&c, sizeof(uint32_t) * len_words() * T) != hipSuccess) {
+            (void)hipFree(d);
+            return false;
+        }
+        (void)hipFree(Dq);
+        (void)hipFree(cntg);
+        Dq = d;
+        cntg = c;
+        run_hours = T;
+        return true;
     }
 
     void release()
@@ -1222,6 +1289,7 @@ struct GroupedWork {
         if (maxn) (void)hipFree(maxn);
         maxn = nullptr;
         n = 0;
+        run_hours = 1;
         buckets0_valid = false;
     }
 
@@ -1309,6 +1377,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
         w.buckets0_valid = true;
     }
+    // travel times: from the runs, by one launch per hour -- or, when the runs of all hours fit, by one launch at the end
+    const bool history = travel && !ivp && w.ensure_history();
     const int G = pack_guide_bits(Z);
     const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G));
     const int64_t mean = (n + Z - 1) / Z;
@@ -1331,8 +1401,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.cdf_t = tb.cdf + static_cast<size_t>(t) * Z * tb.Zp;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
-        a.D = w.Dq;
-        a.cntg = w.cntg;
+        a.D = w.Dq + (history ? w.run_words() * t : 0);
+        a.cntg = w.cntg + (history ? w.len_words() * t : 0);
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.status = status;
@@ -1359,26 +1429,41 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if (grouped) grouped_launch_heavy(a, mean, stream);
         if (!last_hour) {
             prof_begin(CPM_PROFILE_PLACE);
-            grouped_launch_place(stream, w.Dq, w.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next, ids_next, status);
+            grouped_launch_place(stream, a.D, a.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next, ids_next, status);
             prof_end(CPM_PROFILE_PLACE);
             ids = ids_next;
             cnt = cnt_next;
         }
-        if (travel && grouped) {
+        if (travel && grouped && !history) {
             TravelArgs tr{};
-            tr.tt_t = tb.tt + static_cast<size_t>(t) * Z * Z;
+            tr.tt = tb.tt;
             tr.tt_part = w.tt_part;
-            tr.T = T;
-            tr.t = t;
+            tr.d_stride = tr.c_stride = 0;
+            tr.t0 = t;
             tr.gshift = static_cast<int>(w.gshift);
-            tr.step = step;
+            tr.step0 = step;
             tr.cars = cars;
             tr.seed = seed;
             prof_begin(CPM_PROFILE_TRAVEL);
-            hipLaunchKernelGGL(k_grouped_travel, dim3(Z), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+            hipLaunchKernelGGL(k_grouped_travel, dim3(Z, 1), dim3(256), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             prof_end(CPM_PROFILE_TRAVEL);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
+    }
+    if (history) {  // every hour's drivers are still in their runs: one launch
+        TravelArgs tr{};
+        tr.tt = tb.tt;
+        tr.tt_part = w.tt_part;
+        tr.d_stride = w.run_words();
+        tr.c_stride = w.len_words();
+        tr.t0 = 0;
+        tr.gshift = static_cast<int>(w.gshift);
+        tr.step0 = static_cast<uint32_t>(T - 1);
+        tr.cars = cars;
+        tr.seed = seed;
+        prof_begin(CPM_PROFILE_TRAVEL);
+        hipLaunchKernelGGL(k_grouped_travel, dim3(Z, T), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        prof_end(CPM_PROFILE_TRAVEL);
     }
     if (travel && !ivp) {  // the partial sums of k_grouped_travel -> the sum word of the count tensor
         hipLaunchKernelGGL(k_grouped_travel_finish, dim3(1), dim3(kTravelParts), 0, stream, w.tt_part, tt_sum);

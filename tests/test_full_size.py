@@ -98,7 +98,7 @@ def test_model_selection_grid_of_256_points_at_melbourne_size(cpm, O):
         s.init_states(C, cpz)
         init = s.solve_ivp(SIM_SEED)                                   # once; every point restarts from it
         ev = ms.Evaluator(s, C, SIM_SEED, measured_act, measured_park, travel=True)
-        per_rank = [ms.grid_sweep(ev, grid, rank=r, world_size=world, gather=False) for r in range(world)]
+        per_rank = [ms.grid_sweep(ev, grid, rank=r, world_size=world, gather=False, checksums=True) for r in range(world)]
         results = []
         for i in range(len(grid)):
             owners = [r for r in range(world) if per_rank[r][i] is not None]

@@ -64,7 +64,7 @@ for k in sorted(set(fetch) | set(write)):
 sweep = one("sweep/**/*_kernel_stats.csv")
 if sweep:
     shutil.copy(sweep, os.path.join(dst, f"{name}_sweep_kernel_stats.csv"))
-    lines += ["", "## Model-selection sweep (tools/sweep_bench.py --points 16: Z = 2,357 x 1,000 cars/zone, travel times on, table rebuilds per point)", "",
+    lines += ["", "## Model-selection sweep (tools/sweep_bench.py: Z = 2,357 x 1,000 cars/zone, travel times on, table rebuilds per point)", "",
               "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
     for r in list(csv.DictReader(open(sweep)))[:14]:
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['Percentage']):.1f} |")

@@ -17,7 +17,8 @@ import _synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=2357)
 ap.add_argument("--cpz", type=int, default=1000)
-ap.add_argument("--points", type=int, default=32)
+ap.add_argument("--points", type=int, default=32, help="(kept for old command lines; the share of one rank of --world is what is timed)")
+ap.add_argument("--world", type=int, default=8)
 args = ap.parse_args()
 Z, T, cpz = args.zones, 24, args.cpz
 C = Z * cpz
@@ -36,12 +37,13 @@ with cpm.Sampler(Z, T) as s:
     s.solve_ivp(0x5EEDCA125, want=False)
     print(f"IVP {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
     ev = ms.Evaluator(s, C, 0x5EEDCA125, rng.uniform(0, 1, T), rng.uniform(0, 1, (Z, T)), travel=True)
-    grid = ms.make_grid()[:: max(1, 256 // args.points)][: args.points]
+    grid = ms.make_grid()                                # the 256 points of BASELINE.json configs[4]
     ms.grid_sweep(ev, grid[:2])
-    t0 = time.perf_counter()
-    res = ms.grid_sweep(ev, grid)
-    dt = time.perf_counter() - t0
-    print(f"{len(grid)} grid points in {dt:.2f} s = {1e3 * dt / len(grid):.1f} ms/point "
-          f"({len(grid) * C * T / dt:.3e} car-steps/s incl. table rebuilds); "
-          f"256 points on 8 GPUs ~ {32 * dt / len(grid):.1f} s", flush=True)
+    for rank in (0, args.world - 1):                     # what one rank of the 8-GPU job does: its block of the grid, ordered by e_dest
+        t0 = time.perf_counter()
+        res = [r for r in ms.grid_sweep(ev, grid, rank=rank, world_size=args.world, gather=False) if r is not None]
+        dt = time.perf_counter() - t0
+        print(f"rank {rank} of {args.world}: {len(res)} grid points in {dt:.3f} s = {1e3 * dt / len(res):.2f} ms/point "
+              f"({len(res) * C * T / dt:.3e} car-steps/s incl. table rebuilds, travel times, counts to the host and the objectives); "
+              f"e_dest values {sorted({r['e_dest'] for r in res})}", flush=True)
     print("sample:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in res[0].items()})
