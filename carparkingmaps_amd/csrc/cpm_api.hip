@@ -87,6 +87,7 @@ struct cpm_ctx {
     bool have_state = false;
     // results
     int64_t *d_counts = nullptr;  // [2*T*Z + 2]
+    int64_t *h_counts = nullptr;  // pinned twin: the blocking calls bring the whole tensor (status word included) over in one copy
     int *d_err = nullptr;
     // zone-bucket paths
     cpm::ExactWork zx;
@@ -504,6 +505,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counts), sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 2 * sizeof(long long));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->status_ev, hipEventDisableTiming);
     if (e == hipSuccess) c->h_status[0] = c->h_status[1] = 0;
@@ -540,6 +542,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     c->zx.release();
     c->zg.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_ivp_status) (void)hipHostFree(c->h_ivp_status);
     if (c->status_ev) (void)hipEventDestroy(c->status_ev);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -1095,35 +1098,30 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
     }
     if (compat) c->kernel = CPM_KERNEL_CAR;  // the per-hour records of every car are kept by this path
     int32_t rc = resample_enqueue(c, seed, flags, c->d_counts);
-    size_t zt = static_cast<size_t>(c->Z * c->T);
-    if (rc == CPM_OK) {  // a fixed-stride bucket outgrew its region (pathological skew): redo on the exact layout
-        int64_t status = 0;
-        HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t zt = static_cast<size_t>(c->Z * c->T), nwords = 2 * zt + 2;
+    auto fetch = [&]() -> int32_t {  // the count tensor, Σ time and the status word: one copy into pinned memory, one wait
+        HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(int64_t) * nwords, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));  // (how the next grouped step is launched)
         c->status_pending = false;  // this step's status word is dealt with here: resample_enqueue must not grow the regions for it again
-        // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
-        while (status != 0 && rc == CPM_OK && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
-            rc = resample_enqueue(c, seed, flags, c->d_counts);
-            if (rc != CPM_OK) break;
-            HIP_TRY(hipMemcpyAsync(&status, c->d_counts + 2 * zt + 1, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->status_pending) c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));
-            c->status_pending = false;
-        }
-        if (status != 0 && rc == CPM_OK) {  // ... else on the exact layout
-            if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) c->grouped_overflowed = true;
-            c->kernel = cpm::exact_path_fits(static_cast<int>(c->Z)) ? CPM_KERNEL_ZONE_LDS : CPM_KERNEL_CAR;
-            rc = resample_enqueue(c, seed, flags, c->d_counts);
-        }
+        return CPM_OK;
+    };
+    if (rc == CPM_OK) rc = fetch();
+    // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
+    while (rc == CPM_OK && c->h_counts[nwords - 1] != 0 && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
+        rc = resample_enqueue(c, seed, flags, c->d_counts);
+        if (rc == CPM_OK) rc = fetch();
+    }
+    if (rc == CPM_OK && c->h_counts[nwords - 1] != 0) {  // ... else on a layout that cannot overflow
+        if (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED) c->grouped_overflowed = true;
+        c->kernel = cpm::exact_path_fits(static_cast<int>(c->Z)) ? CPM_KERNEL_ZONE_LDS : CPM_KERNEL_CAR;
+        rc = resample_enqueue(c, seed, flags, c->d_counts);
+        if (rc == CPM_OK) rc = fetch();
     }
     if (rc != CPM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(parking, c->d_counts, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(driving, c->d_counts + zt, sizeof(int64_t) * zt, hipMemcpyDeviceToHost, c->stream));
-    int64_t tt = 0;
-    HIP_TRY(hipMemcpyAsync(&tt, c->d_counts + 2 * zt, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (sum_tt_q16) *sum_tt_q16 = tt;
+    std::memcpy(parking, c->h_counts, sizeof(int64_t) * zt);
+    std::memcpy(driving, c->h_counts + zt, sizeof(int64_t) * zt);
+    if (sum_tt_q16) *sum_tt_q16 = c->h_counts[2 * zt];
     if (compat && c->n > 0) {
         // one hour column at a time: state[:,t] and trans[:,t,1..4] are contiguous runs of C values
         int64_t n = c->n;

@@ -81,24 +81,66 @@ class Evaluator:
     measured_parking: object = None
     travel: bool = True
     _e_dest: object = field(default=None, repr=False)
+    _pipe: object = field(default=None, repr=False)
 
-    def evaluate(self, pt):
+    def _install(self, pt):
         s = self.sampler
-        s.build_p_drive(pt.p_min, pt.p_max, pt.e_drive, want=False)
+        s.build_p_drive(pt.p_min, pt.p_max, pt.e_drive, want=False)   # (Z x T work: the Z x Z x T mean is cached by the library)
         key = (type(pt.e_dest).__name__, float(pt.e_dest))
-        if key != self._e_dest:              # the CDF is rebuilt only when e_dest changes
+        if key != self._e_dest:              # the CDF and the row packs are rebuilt only when e_dest changes
             s.build_p_dest(pt.e_dest, want=False)
             self._e_dest = key
-        r = s.resample(self.seed, travel=self.travel)
-        act = traffic_activity(r["driving"])
+
+    def _objectives(self, pt, parking, driving, sum_tt_q16):
+        act = traffic_activity(driving)
         out = {"e_drive": pt.e_drive, "p_min": pt.p_min, "p_max": pt.p_max, "e_dest": float(pt.e_dest),
-               "A_drive": a_drive(r["sum_tt_q16"], self.C, s.T), "traffic_activity": act,
-               "parking": r["parking"], "driving": r["driving"]}
+               "A_drive": a_drive(sum_tt_q16, self.C, self.sampler.T), "traffic_activity": act,
+               "parking": parking, "driving": driving}
         if self.measured_activity is not None:
             out["activity_error"] = traffic_activity_error(act, self.measured_activity)
         if self.measured_parking is not None:
-            out["parking_error"] = parking_density_error(r["parking"], self.C, self.measured_parking)
+            out["parking_error"] = parking_density_error(parking, self.C, self.measured_parking)
         return out
+
+    def evaluate(self, pt):
+        """One point, blocking."""
+        self._install(pt)
+        r = self.sampler.resample(self.seed, travel=self.travel)
+        return self._objectives(pt, r["parking"], r["driving"], r["sum_tt_q16"])
+
+    # -- pipelined form: point k+1 runs on the GPU while the host reduces point k (two count tensors, pinned host twins) --
+    def begin(self, pt, slot):
+        """Enqueue the table update, the resample and the copy of its counts to the host for `pt`; returns at once."""
+        import torch
+        s = self.sampler
+        if self._pipe is None:
+            stream = torch.cuda.Stream(device=s.device)
+            s.set_stream(stream.cuda_stream)
+            n = s.counts_words()
+            self._pipe = dict(stream=stream,
+                              dev=[torch.zeros(n, dtype=torch.int64, device=f"cuda:{s.device}") for _ in range(2)],
+                              host=[torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)],
+                              done=[torch.cuda.Event() for _ in range(2)])
+        p = self._pipe
+        self._install(pt)
+        with torch.cuda.stream(p["stream"]):
+            s.resample_dev(self.seed, p["dev"][slot].data_ptr(), travel=self.travel)
+            p["host"][slot].copy_(p["dev"][slot], non_blocking=True)
+            p["done"][slot].record(p["stream"])
+
+    def finish(self, pt, slot):
+        """Wait for `begin(pt, slot)` and reduce its counts.  A step whose status word is set (a bucket region overflowed: the
+        asynchronous form cannot repeat itself) is evaluated again through the blocking call, which grows the regions."""
+        p = self._pipe
+        p["done"][slot].synchronize()
+        flat = p["host"][slot].numpy()
+        Z, T = self.sampler.Z, self.sampler.T
+        zt = Z * T
+        if flat[2 * zt + 1] != 0:
+            return self.evaluate(pt)
+        parking = flat[:zt].reshape((Z, T), order="F").copy()
+        driving = flat[zt:2 * zt].reshape((Z, T), order="F").copy()
+        return self._objectives(pt, parking, driving, int(flat[2 * zt]))
 
 
 # ------------------------------------------------------------------ the reference's three searches
@@ -182,8 +224,18 @@ def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True, checksums=Fal
     by_e_dest = sorted(range(len(grid)), key=lambda i: (float(grid[i].e_dest), type(grid[i].e_dest).__name__, i))
     mine = points_of_rank(len(grid), rank, world_size, by_e_dest)
     local = {}
-    for i in mine:
-        r = evaluator.evaluate(grid[i])
+
+    def results():  # point k+1 is enqueued before point k is reduced on the host
+        prev = None
+        for k, i in enumerate(mine):
+            evaluator.begin(grid[i], k & 1)
+            if prev is not None:
+                yield prev[0], evaluator.finish(grid[prev[0]], prev[1])
+            prev = (i, k & 1)
+        if prev is not None:
+            yield prev[0], evaluator.finish(grid[prev[0]], prev[1])
+
+    for i, r in results():
         local[i] = {k: v for k, v in r.items() if np.isscalar(v)}
         local[i]["driving_total"] = int(r["driving"].sum())
         local[i]["hours_hold_all_cars"] = bool((r["parking"].sum(axis=0) == evaluator.C).all())
