@@ -229,6 +229,11 @@ struct GroupedArgs {
     uint64_t seed;
 };
 
+// A barrier for LDS data only: this wave's LDS operations have completed, then the workgroup meets.  __syncthreads() is also a
+// workgroup-scope fence, for which hipcc waits until the wave's global stores and ATOMICS have completed (s_waitcnt vmcnt(0)) -- a
+// memory round trip in front of every barrier that follows a ticket or a store, although only LDS contents change hands there.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 
@@ -276,7 +281,9 @@ __device__ __noinline__ uint32_t search_exact_row(const double *__restrict__ cdf
 // walk that needs no upper clamp: with 2^K > n,  for s = 2^(K-1) .. 1:  if (hi[L + o + s - 1] < khi) o += s  ends at o = the
 // number of entries from L on that lie below khi = the answer's offset (<= n <= 2^K - 1; the largest index read is L + 2^K - 2).
 // K is wave-uniform (the widest bracket among the wave's draws decides): three to five steps of
-// {LDS read, compare, select, add} on the dense synthetic rows.  Brackets of 32 entries and more (rows with long runs of
+// {LDS read, compare, select, add} on the dense synthetic rows.  (Two strides per round trip -- three independent probes, the
+// highest one below the draw wins -- shortened the dependent chain and lengthened the launch, 27.5 us against 26.8: the kernel is
+// bound by what it issues, not by this latency; profiles/round2_notes.md.)  Brackets of 32 entries and more (rows with long runs of
 // zero-probability zones) take the same walk from a larger K with the probe index clamped to the row.
 template <int CPT>
 __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint32_t *hi_g, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
@@ -380,17 +387,47 @@ constexpr int kHeavyCap = 4096;  // zones the heavy kernel can be handed in one 
 #else
 #define CPM_SGPR_ATTR
 #endif
-// Diagnostic builds (-DCPM_DIAGNOSTIC, never the product): s_memtime stamps of thread 0 of every placing block into a side buffer
+// Diagnostic builds (-DCPM_DIAGNOSTIC, never the product): s_memtime stamps of thread 0 of every block, kept in scalar registers
+// and written to a side buffer when the block ends (a stamp that loaded the buffer's address on the spot made hipcc wait for every
+// outstanding load and atomic in front of it: the timeline showed the stamps, not the kernel).
 #ifdef CPM_DIAGNOSTIC
 __device__ unsigned long long *g_place_stamps = nullptr;  // [blocks][8], set by cpm_diag_place_stamps
-#define CPM_PSTAMP(k)                                                                                              \
-    do {                                                                                                           \
-        if (threadIdx.x == 0 && g_place_stamps) g_place_stamps[static_cast<size_t>(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+#define CPM_STAMP_DECL_IMPL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CPM_STAMP_IMPL(k) st_[k] = __builtin_amdgcn_s_memtime()
+#define CPM_STAMP_FLUSH_IMPL                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && g_place_stamps) {                                                     \
+            _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) g_place_stamps[static_cast<size_t>(blockIdx.x) * 8 + k_] = st_[k_]; \
+        }                                                                                             \
     } while (0)
 #else
-#define CPM_PSTAMP(k) \
-    do {              \
+#define CPM_STAMP_DECL_IMPL \
+    do {                    \
     } while (0)
+#define CPM_STAMP_IMPL(k) \
+    do {                  \
+    } while (0)
+#define CPM_STAMP_FLUSH_IMPL \
+    do {                     \
+    } while (0)
+#endif
+#define CPM_STAMP_NONE \
+    do {               \
+    } while (0)
+#ifdef CPM_STAMP_SAMPLER  // (the same side buffer, filled by the sampler instead of the placing kernel: -DCPM_DIAGNOSTIC -DCPM_STAMP_SAMPLER)
+#define CPM_SSTAMP_DECL CPM_STAMP_DECL_IMPL
+#define CPM_SSTAMP(k) CPM_STAMP_IMPL(k)
+#define CPM_SSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
+#define CPM_PSTAMP_DECL CPM_STAMP_NONE
+#define CPM_PSTAMP(k) CPM_STAMP_NONE
+#define CPM_PSTAMP_FLUSH CPM_STAMP_NONE
+#else
+#define CPM_SSTAMP_DECL CPM_STAMP_NONE
+#define CPM_SSTAMP(k) CPM_STAMP_NONE
+#define CPM_SSTAMP_FLUSH CPM_STAMP_NONE
+#define CPM_PSTAMP_DECL CPM_STAMP_DECL_IMPL
+#define CPM_PSTAMP(k) CPM_STAMP_IMPL(k)
+#define CPM_PSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
 #endif
 
 template <int BLOCK, int CPT, int NQ, bool GROUPED>
@@ -410,6 +447,8 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     // (ROCm 7.2) drains vmcnt to 0 at the first use of any ordinary vector load result, which would put Philox behind the whole
     // pack.  The wave issues CPT + 1 id loads, then exactly NQ LDS-DMA instructions; vmcnt retires in order, so vmcnt <= NQ
     // means the ids are in their registers.
+    CPM_SSTAMP_DECL;
+    CPM_SSTAMP(0);
     const uint32_t n_raw = a.cnt[z];
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     }
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
+    CPM_SSTAMP(1);
     const uint32_t n_all = min(n_raw, cap);
     // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
     // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
@@ -463,8 +503,10 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     }
     // This wave's pieces of the pack have landed (LDS-DMA counts in vmcnt; s_barrier itself waits for no counter), then the
     // barrier makes every wave's pieces visible to every wave.
+    CPM_SSTAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    CPM_SSTAMP(3);
     const uint32_t n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
@@ -488,6 +530,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
                 if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
         }
     }
+    CPM_SSTAMP(4);
     if (GROUPED) {
         // stayers: one ticket per wave for all its CPT slots
         unsigned long long mS[CPT];
@@ -562,7 +605,9 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
         if (lane == 0 && nd) atomicAdd(&s_ndrive, nd);
     }
-    __syncthreads();  // ranks, staged drivers and counters are final
+    CPM_SSTAMP(5);
+    lds_barrier();  // ranks, staged drivers and counters (all in LDS) are final; the stayers' stores need not have landed
+    CPM_SSTAMP(6);
     if (GROUPED) {
         // staged drivers -> their runs: 16 lanes per group, 64 B per store
         for (int g = tid >> 4; g < kGroups; g += BLOCK / 16) {
@@ -579,6 +624,8 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         a.driving_t[z] = GROUPED ? n - s_nstay : s_ndrive;  // every car of the bucket either stays or drives
         if (GROUPED) a.cnt_next[z] = s_nstay;  // k_grouped_place adds the arrivals
     }
+    CPM_SSTAMP(7);
+    CPM_SSTAMP_FLUSH;
 }
 
 // The rest of the HEAVY buckets (real Uber Movement tables are peaky: a central zone can hold tens of times the mean, and one
@@ -742,6 +789,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
     const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
     const int sub = tid >> 4, l16 = tid & 15;
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    CPM_PSTAMP_DECL;
     CPM_PSTAMP(0);
     for (int k = tid; k < zpg; k += kPlaceBlock) {
         bins[k] = 0;
@@ -758,7 +806,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
 #pragma unroll
         for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
     }
-    __syncthreads();
+    lds_barrier();
     CPM_PSTAMP(1);
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {
@@ -783,7 +831,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
         }
     }
     CPM_PSTAMP(2);
-    __syncthreads();
+    lds_barrier();
     CPM_PSTAMP(3);
     // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
     auto surplus_entry = [&](uint32_t e) -> uint32_t {
@@ -805,12 +853,12 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
             if (lane >= o) incl += up;
         }
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wsum[w];
         if (tid < kRuns) lstart[tid] = before + incl - len;
         if (tid == kRuns - 1) lstart[kRuns] = before + incl;
-        __syncthreads();
+        lds_barrier();
         ltotal = lstart[kRuns];
         for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {  // (a thread's kSurplusBatch loads are in flight together)
             uint32_t w[kSurplusBatch];
@@ -820,7 +868,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
             for (int u = 0; u < kSurplusBatch; ++u)
                 if (e0 + u * kPlaceBlock < ltotal) atomicAdd(&tbins[w[u] >> idbits], 1u);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // The ticket (this block's range inside each bucket of the group) is requested now and needed only when the sorted list is
     // written out: its round trip runs under the block scan of the histogram (the zones' offsets in the sorted list) and the sort.
@@ -836,7 +884,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
             if (lane >= o) incl += up;
         }
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wsum[w];  // (16 waves)
         first = before + incl - cr;
@@ -844,7 +892,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
         if (tid == kPlaceBlock - 1) s_total = before + incl;
     }
     CPM_PSTAMP(4);
-    __syncthreads();
+    lds_barrier();
     CPM_PSTAMP(5);
     // pass B: the entries held in registers go to their place in the sorted list
 #pragma unroll
@@ -863,7 +911,8 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
         tbins[tid] = base + cr;
         delta[tid] = base - first;  // (wraps; only base - first + index is used)
     }
-    __syncthreads();
+    CPM_PSTAMP(6);
+    lds_barrier();
     // the sorted list out: consecutive lanes, consecutive slots of one bucket ...
     const uint32_t total = s_total;
     for (uint32_t i = tid; i < total; i += kPlaceBlock) {
@@ -884,7 +933,11 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
                 if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w[u] & idmask;
             }
     }
-    CPM_PSTAMP(6);
+    CPM_PSTAMP(7);
+#if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER)
+    st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
+#endif
+    CPM_PSTAMP_FLUSH;
 }
 
 // Geometry of a placing launch: threads per block, runs per 16-lane group (KRUNS = 4 or 8), blocks per destination group

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=4096)
 ap.add_argument("--cpz", type=int, default=1000)
 ap.add_argument("--seeds", type=int, default=40)
+ap.add_argument("--skew", type=int, default=0, help="Q > 0: skewed destination popularity 1 / (Q + rank): heavy buckets, grown regions, long runs")
 args = ap.parse_args()
 Z, T, cpz = args.zones, 24, args.cpz
 C = Z * cpz
@@ -22,7 +23,7 @@ bad = 0
 t0 = time.perf_counter()
 with cpm.Sampler(Z, T) as a, cpm.Sampler(Z, T) as b:
     for s in (a, b):
-        s.synth_tables(0x5EED7AB1E)
+        s.synth_tables(0x5EED7AB1E, skew_q=args.skew)
     b.set_kernel(cpm.CPM_KERNEL_CAR)
     for k in range(args.seeds):
         seed = 0x5EEDCA125 + 7919 * k
@@ -36,5 +37,6 @@ with cpm.Sampler(Z, T) as a, cpm.Sampler(Z, T) as b:
         bad += not same
         if not same or k % 10 == 0:
             print(f"seed {k}: {'equal' if same else 'DIFFERENT'}  ({time.perf_counter() - t0:.1f} s)", flush=True)
-    print(f"{args.seeds} seeds, {bad} mismatches; grouped path regions {a.get_info(2)}x the mean, kernel {a.get_info(1)}")
+    print(f"Z={Z} cpz={cpz} skew={args.skew}: {args.seeds} seeds, {bad} mismatches; grouped path regions {a.get_info(2)}x the mean, "
+          f"heavy-bucket parts {a.get_info(3)}, kernel {a.get_info(1)}, largest bucket {int(res[0][1].max())}")
 sys.exit(1 if bad else 0)
