@@ -17,6 +17,8 @@
 #include "cpm_grouped.h"
 #include "cpm_ingest.h"
 
+static hipError_t ensure_stream(cpm_ctx *c);
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -40,9 +42,14 @@ int32_t fail(int32_t code, const char *fmt, ...)
                         hipGetErrorString(e_), __FILE__, __LINE__);                            \
     } while (0)
 
+// Every entry that enqueues work: the context's device is current and the context has a stream (its own one is created on first
+// need -- a HIP stream takes one of the process's few hardware queues when it is CREATED, GPU_MAX_HW_QUEUES = 4 by default, and
+// streams beyond that share queues: two contexts that were each given a caller's stream before doing anything hold two queues and
+// their resamples interleave on the chip; with two unused own streams in between they were measured to serialise).
 #define CTX_TRY(ctx)                                                 \
     if (!(ctx)) return fail(CPM_ERR_ARG, "null context");            \
-    HIP_TRY(hipSetDevice((ctx)->device))
+    HIP_TRY(hipSetDevice((ctx)->device));                            \
+    HIP_TRY(ensure_stream(ctx))
 
 template <typename T>
 void dfree(T *&p)
@@ -60,8 +67,9 @@ struct cpm_ctx {
     int Zp = 0;
     int device = 0;
     int cu_count = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;  // created on first need (ensure_stream)
+    hipStream_t stream = nullptr;      // what the context enqueues on: the caller's (cpm_set_stream) or own_stream
+    bool have_stream = false;
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
     double *d_cdf = nullptr;     // [T][Z][Zp]
@@ -114,6 +122,19 @@ struct cpm_ctx {
     std::vector<hipEvent_t> ev;  // 2 per hourly launch
     int n_prof = 0;
 };
+
+static hipError_t ensure_stream(cpm_ctx *c)
+{
+    if (c->have_stream) return hipSuccess;
+    if (!c->own_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    c->stream = c->own_stream;
+    c->have_stream = true;
+    return hipSuccess;
+}
+
 
 namespace {
 
@@ -501,8 +522,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->cu_count = p.multiProcessorCount;
     if (c->cu_count <= 0) c->cu_count = 256;
-    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&c->d_err, sizeof(int));
+    hipError_t e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counts), sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
@@ -515,7 +535,6 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
-    c->stream = c->own_stream;
     *ctx_out = c;
     return CPM_OK;
 }
@@ -524,7 +543,7 @@ int32_t cpm_destroy(cpm_ctx *c)
 {
     if (!c) return CPM_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->have_stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_pdrive);
     dfree(c->d_cdf);
     dfree(c->d_hi);
@@ -553,7 +572,7 @@ int32_t cpm_destroy(cpm_ctx *c)
 
 int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
 {
-    CTX_TRY(c);
+    if (!c) return fail(CPM_ERR_ARG, "null context");  // (host state only: no stream is needed, none is created)
     switch (option) {
     case CPM_OPT_KERNEL:
         if (value != CPM_KERNEL_AUTO && value != CPM_KERNEL_CAR && value != CPM_KERNEL_ZONE_LDS && value != CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
@@ -594,13 +613,15 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
 
 int32_t cpm_set_stream(cpm_ctx *c, void *hip_stream)
 {
-    CTX_TRY(c);
-    {
+    if (!c) return fail(CPM_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->have_stream) {  // whatever was enqueued so far is finished on the stream it was enqueued on
         int32_t rc_ivp = finish_ivp(c);
         if (rc_ivp != CPM_OK) return rc_ivp;
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    c->have_stream = hip_stream != nullptr;  // NULL: the context's own stream, created when it is first needed
     return CPM_OK;
 }
 

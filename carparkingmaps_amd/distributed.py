@@ -68,18 +68,18 @@ class ShardedSampler:
         self.world_size = dist.get_world_size() if world_size is None else world_size
         self.device = torch.cuda.current_device() if device is None else device
         self.deal = deal
-        self.s = Sampler(number_zones, T, self.device)
+        # One explicit torch stream carries the kernels; the collective is ordered behind them by torch (it waits for the work
+        # enqueued on the current stream) without a host synchronisation.  (torch's default stream has handle 0, which the C ABI
+        # reads as "use the context's own stream" -- never rely on it.)  Handed over at construction: the context then never
+        # creates a stream of its own (hardware queues are few; Sampler.__init__).
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.s = Sampler(number_zones, T, self.device, stream=self.stream)
         self.Z, self.T = int(number_zones), int(T)
         dev = f"cuda:{self.device}"
         self._bufs = [torch.zeros(self.s.counts_words(), dtype=torch.int64, device=dev) for _ in range(2)]
         self._work = [None, None]
         self._k = 0
         self.counts = self._bufs[0]
-        # One explicit torch stream carries the kernels; the collective is ordered behind them by torch (it waits for the work
-        # enqueued on the current stream) without a host synchronisation.  (torch's default stream has handle 0, which the C ABI
-        # reads as "use the context's own stream" -- never rely on it.)
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.s.set_stream(self.stream.cuda_stream)
         torch.cuda.synchronize(self.device)  # counts zero-filled before the first enqueue on self.stream
 
     def init_states(self, C_total, cars_per_zone):

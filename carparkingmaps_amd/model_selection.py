@@ -48,18 +48,22 @@ def a_drive(sum_tt_q16, C, T=24):
 def parking_density_error(parking, C, measured):
     """README.md:2219-2244: per-zone min-max normalisation over the day (zones with max == min are
     left as they are), MSE over 24 h for zones that are measured (row sum != 0) and not flat, averaged
-    over the validated zones."""
-    p = np.asarray(parking, dtype=np.float64) / C
-    m = np.asarray(measured, dtype=np.float64)
-    lo, hi = p.min(axis=1, keepdims=True), p.max(axis=1, keepdims=True)
-    flat = (hi == lo)[:, 0]
-    with np.errstate(all="ignore"):
-        pn = np.where(flat[:, None], p, (p - lo) / (hi - lo))
-    valid = (m.sum(axis=1) != 0) & ~flat
+    over the validated zones.  (Evaluated hour-major -- the count tensor's own layout, Z contiguous -- so that a point of
+    the sweep costs the host tens of microseconds, not half a millisecond: with two contexts in flight the host is what
+    a point waits for.)"""
+    p = np.asarray(parking).T / float(C)                     # (T, Z); a view of a Julia-ordered (Z, T) array is contiguous this way
+    m = np.asarray(measured, dtype=np.float64).T
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    flat = hi == lo
+    valid = (m.sum(axis=0) != 0) & ~flat
     if not valid.any():
         return float("nan")
-    err = ((pn[valid] - m[valid]) ** 2).sum(axis=1) / p.shape[1]
-    return float(err.sum() / valid.sum())
+    if not valid.all():
+        p, m, lo, hi = p[:, valid], m[:, valid], lo[valid], hi[valid]
+    pn = (p - lo) / (hi - lo)
+    d = pn - m
+    err = (d * d).sum(axis=0) / p.shape[0]
+    return float(err.sum() / err.size)
 
 
 # ------------------------------------------------------------------ one evaluation
@@ -82,6 +86,10 @@ class Evaluator:
     travel: bool = True
     _e_dest: object = field(default=None, repr=False)
     _pipe: object = field(default=None, repr=False)
+
+    def __post_init__(self):
+        if self.measured_parking is not None:   # Julia order, like the count tensors: the error is evaluated hour-major on contiguous rows
+            self.measured_parking = np.asfortranarray(np.asarray(self.measured_parking, dtype=np.float64))
 
     def _install(self, pt):
         s = self.sampler
@@ -114,8 +122,9 @@ class Evaluator:
         import torch
         s = self.sampler
         if self._pipe is None:
-            stream = torch.cuda.Stream(device=s.device)
-            s.set_stream(stream.cuda_stream)
+            if s._stream is None:     # (a Sampler that was given its stream at construction keeps it; see Sampler.__init__)
+                s.set_stream(torch.cuda.Stream(device=s.device))
+            stream = s._stream_obj if hasattr(s._stream_obj, "cuda_stream") else torch.cuda.ExternalStream(s._stream, device=s.device)
             n = s.counts_words()
             self._pipe = dict(stream=stream,
                               dev=[torch.zeros(n, dtype=torch.int64, device=f"cuda:{s.device}") for _ in range(2)],
@@ -138,8 +147,9 @@ class Evaluator:
         zt = Z * T
         if flat[2 * zt + 1] != 0:
             return self.evaluate(pt)
-        parking = flat[:zt].reshape((Z, T), order="F").copy()
-        driving = flat[zt:2 * zt].reshape((Z, T), order="F").copy()
+        both = flat[:2 * zt].copy()                           # (the pinned twin is reused two points later)
+        parking = both[:zt].reshape((T, Z)).T                 # Julia order (Z, T): views, no second copy
+        driving = both[zt:].reshape((T, Z)).T
         return self._objectives(pt, parking, driving, int(flat[2 * zt]))
 
 
@@ -220,25 +230,42 @@ def points_of_rank(n_points, rank, world_size, order=None):
 
 def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True, checksums=False):
     """Evaluate this rank's share of `grid`; returns a list (on every rank when gather) of dicts with the
-    per-point scalars, ordered like `grid` (checksums: also CRC-32 of both count tensors, for the tests)."""
+    per-point scalars, ordered like `grid` (checksums: also CRC-32 of both count tensors, for the tests).
+
+    `evaluator` may be a list of Evaluators on the same GPU (each with its own Sampler context, hence its own stream): the
+    rank's slice is cut into as many contiguous pieces and the pieces advance in turn, so that a point of every context is on
+    the GPU at any time.  A resample is a serial chain of an issue-bound sampler launch and a latency-bound placing launch
+    per hour; two independent chains interleave on the chip (measured at S4k: 1.41 ms for two resamples side by side
+    against 2 x 0.92 one after the other, profiles/round2_notes.md) -- the hours of ONE resample cannot."""
+    lanes = list(evaluator) if isinstance(evaluator, (list, tuple)) else [evaluator]
+    C = lanes[0].C
     by_e_dest = sorted(range(len(grid)), key=lambda i: (float(grid[i].e_dest), type(grid[i].e_dest).__name__, i))
     mine = points_of_rank(len(grid), rank, world_size, by_e_dest)
     local = {}
 
-    def results():  # point k+1 is enqueued before point k is reduced on the host
+    def lane_results(ev, pts):  # point k+1 is enqueued before point k is reduced on the host
         prev = None
-        for k, i in enumerate(mine):
-            evaluator.begin(grid[i], k & 1)
+        for k, i in enumerate(pts):
+            ev.begin(grid[i], k & 1)
             if prev is not None:
-                yield prev[0], evaluator.finish(grid[prev[0]], prev[1])
+                yield prev[0], ev.finish(grid[prev[0]], prev[1])
             prev = (i, k & 1)
         if prev is not None:
-            yield prev[0], evaluator.finish(grid[prev[0]], prev[1])
+            yield prev[0], ev.finish(grid[prev[0]], prev[1])
+
+    def results():  # the lanes in turn: each next() enqueues that lane's next point and reduces its previous one
+        gens = [lane_results(ev, points_of_rank(len(mine), l, len(lanes), mine)) for l, ev in enumerate(lanes)]
+        while gens:
+            for g in list(gens):
+                try:
+                    yield next(g)
+                except StopIteration:
+                    gens.remove(g)
 
     for i, r in results():
         local[i] = {k: v for k, v in r.items() if np.isscalar(v)}
         local[i]["driving_total"] = int(r["driving"].sum())
-        local[i]["hours_hold_all_cars"] = bool((r["parking"].sum(axis=0) == evaluator.C).all())
+        local[i]["hours_hold_all_cars"] = bool((r["parking"].sum(axis=0) == C).all())
         if checksums:
             local[i]["parking_crc32"] = zlib.crc32(np.ascontiguousarray(r["parking"].ravel(order="F")).tobytes())
             local[i]["driving_crc32"] = zlib.crc32(np.ascontiguousarray(r["driving"].ravel(order="F")).tobytes())

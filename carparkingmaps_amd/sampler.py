@@ -23,12 +23,19 @@ def _vp(a):
 class Sampler:
     """Device-resident tables + car state for `number_zones` zones and T hours on one GPU."""
 
-    def __init__(self, number_zones, T=24, device=0):
+    def __init__(self, number_zones, T=24, device=0, stream=None):
+        """stream: a HIP stream to enqueue on -- an integer handle or an object with `.cuda_stream` (torch.cuda.Stream), which is
+        kept alive with the Sampler.  Given here, the context never creates a stream of its own: a process has few hardware
+        queues (GPU_MAX_HW_QUEUES, 4 by default) and every HIP stream that is created takes a share of one, so two contexts
+        meant to run side by side should each get their stream at construction (model_selection.grid_sweep over two lanes)."""
         self._L = _lib.load()
         self.Z, self.T, self.device = int(number_zones), int(T), int(device)
         h = C.c_void_p()
         _lib.check(self._L.cpm_create(C.byref(h), self.Z, self.T, self.device))
         self._h = h
+        self._stream_obj = self._stream = None
+        if stream is not None:
+            self.set_stream(stream)
         self.C_total = self.cars_per_zone = self.car_begin = self.car_count = 0
         self.car_stride = 1
 
@@ -66,8 +73,10 @@ class Sampler:
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_PROFILE, int(stride) if on else 0))
 
     def set_stream(self, hip_stream):
-        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        _lib.check(self._L.cpm_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream), an object with `.cuda_stream`, or None."""
+        handle = getattr(hip_stream, "cuda_stream", hip_stream)
+        _lib.check(self._L.cpm_set_stream(self._h, C.c_void_p(handle) if handle else None))
+        self._stream_obj, self._stream = (hip_stream if handle else None), (handle or None)
 
     def sync(self):
         _lib.check(self._L.cpm_sync(self._h))

@@ -100,3 +100,38 @@ def test_grid_points_on_device_match_the_oracle(cpm, O):
         assert got["A_drive"] == ms.a_drive(ref["sum_tt_q16"], C, T)
         assert got["activity_error"] == pytest.approx(ms.traffic_activity_error(ms.traffic_activity(ref["driving"]), measured_act), rel=1e-12)
         assert got["parking_error"] == pytest.approx(ms.parking_density_error(ref["parking"], C, measured_park), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_two_sampler_contexts_in_flight_give_the_same_points(cpm, O):
+    """grid_sweep over two Evaluators (two contexts, two streams: a grid point of each on the GPU at a time) returns what one
+    context returns, point by point and bit by bit."""
+    from carparkingmaps_amd import model_selection as ms
+    Z, cpz = 48, 50
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.4)
+    grid = [ms.Point(a, 0.1, b, d) for d in (1, 2) for a in (0.5, 1.0, 2.0) for b in (0.8, 1.0)]   # 12 points, two e_dest values
+    samplers, lanes = [], []
+    try:
+        import torch
+        for _ in range(2):
+            s = cpm.Sampler(Z, T, stream=torch.cuda.Stream())   # (a lane brings its stream: Sampler.__init__)
+            samplers.append(s)
+            s.set_datamatrix(dm, dist)
+            s.build_p_drive(0.1, 0.9, 0.5, want=False)
+            s.build_p_dest(2, want=False)
+            s.init_states(C, cpz)
+            s.solve_ivp(SIM_SEED, want=False)
+            lanes.append(ms.Evaluator(s, C, SIM_SEED, travel=True))
+        one = ms.grid_sweep(lanes[0], grid, checksums=True)
+        two = ms.grid_sweep(lanes, grid, checksums=True)
+        odd = ms.grid_sweep(lanes, grid[:5], checksums=True)        # 3 + 2 points: the lanes run dry at different times
+    finally:
+        for s in samplers:
+            s.close()
+    keys = ("A_drive", "driving_total", "parking_crc32", "driving_crc32", "hours_hold_all_cars")
+    for a, b in zip(one, two):
+        assert all(a[k] == b[k] for k in keys)
+    for a, b in zip(one[:5], odd):
+        assert all(a[k] == b[k] for k in keys)
+    assert all(r["hours_hold_all_cars"] for r in two)

@@ -62,4 +62,6 @@ if not sampler:
     for name, m in (("long-run path", lng), ("no long run", ~lng)):
         if m.any():
             print(f"  {name}: per-phase (median ticks)", [int(np.median(d[m, k])) for k in range(K - 1)], " whole block:", int(np.median(t[m, K - 1] - t[m, 0])))
+print("per-phase p90 / max:", [int(np.percentile(d[:, k], 90)) for k in range(K - 1)], [int(d[:, k].max()) for k in range(K - 1)],
+      " whole block p90 / max:", int(np.percentile(t[:, K - 1] - t[:, 0], 90)), int((t[:, K - 1] - t[:, 0]).max()))
 print("per-phase durations (median ticks):", [int(np.median(d[:, k])) for k in range(K - 1)], " whole block (median):", int(np.median(t[:, K - 1] - t[:, 0])))
