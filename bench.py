@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--skew", type=int, default=0, help="Q > 0: skewed destination popularity 1 / (Q + rank) (secondary figure; 32 ~ the "
                                                         "most popular zone 26x the mean); 0: the flat headline tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair", action="store_true", help="skip the two-resamples-in-flight figure (profiling runs: its launches overlap, "
+                                                           "which would blur the per-kernel statistics)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -236,7 +238,7 @@ def main():
     # parameter sweep or a run over several seeds does).  The hours of ONE resample are a serial chain of an issue-bound sampler
     # launch and a latency-bound placing launch; two chains interleave on the chip.  Outside the headline's timed region.
     pair_ms = None
-    if world == 1 and kernel_used in (0, 5):
+    if world == 1 and kernel_used in (0, 5) and not args.no_pair:
         st2 = torch.cuda.Stream(device=local_rank)
         s2 = cpm.Sampler(Z, T, local_rank, stream=st2)
         s2.set_kernel(args.kernel)

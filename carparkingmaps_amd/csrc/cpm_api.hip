@@ -73,6 +73,7 @@ struct cpm_ctx {
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
     double *d_cdf = nullptr;     // [T][Z][Zp]
+    double *d_pdest_work = nullptr;  // [T][Z][Z] reference layout: cpm_build_p_dest's p_destin before it becomes the CDF
     uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_grouped.h)
     double *d_last = nullptr;    // [T][Z] row totals
     long long *d_thr = nullptr;  // [T][Z] Bernoulli thresholds of p_drive (k_build_thr), rebuilt whenever p_drive changes
@@ -546,6 +547,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     if (c->have_stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_pdrive);
     dfree(c->d_cdf);
+    dfree(c->d_pdest_work);
     dfree(c->d_hi);
     dfree(c->d_last);
     dfree(c->d_thr);
@@ -920,8 +922,10 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
     }
     if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
-    double *d_p = nullptr;
-    HIP_TRY(hipMalloc(&d_p, bytes));
+    // The p_destin the CDF is summed from, in the reference's layout.  Kept by the context: a sweep calls this entry once per e_dest
+    // value, and allocating and freeing Z x Z x T x 8 B around every call was measured at up to 0.4 s on a box (the kernels: 3 ms).
+    if (!c->d_pdest_work) HIP_TRY(hipMalloc(&c->d_pdest_work, bytes));
+    double *d_p = c->d_pdest_work;
     dim3 g1(nblk(c->Z, 64), static_cast<unsigned>(c->Z));
     hipLaunchKernelGGL(cpm::k_pdest_weights, g1, dim3(64), 0, c->stream, c->d_dm, d_p, static_cast<int>(c->Z),
                        static_cast<int>(c->T), e_dest, e_is_integer);
@@ -932,8 +936,7 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
     int32_t rc = CPM_OK;
     if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));
     if (rc == CPM_OK) rc = build_cdf_from_device(c, d_p);
-    (void)hipStreamSynchronize(c->stream);
-    dfree(d_p);
+    if (out) (void)hipStreamSynchronize(c->stream);  // (the host copy of the table)
     return rc;
 }
 

@@ -93,7 +93,10 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
 #define CPM_INFO_CAP_MULT 2
 #define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above twice a workgroup's slots was seen */
 int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own */
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own, which is created when a call first needs it.
+ * Contexts meant to run side by side (two resamples interleave on the chip) are each given their stream right behind
+ * cpm_create: HIP streams take the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when they are created, and streams
+ * that share a queue run one after the other. */
 int32_t cpm_set_stream(cpm_ctx *ctx, void *hip_stream);
 int32_t cpm_sync(cpm_ctx *ctx);
 

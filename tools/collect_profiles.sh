@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline ${BENCH_ARGS}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pair ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo trace done >> $OUT/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
@@ -18,7 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROO
 echo write done >> $OUT/progress.log
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $ROOT/bench.py $ARGS > $OUT/bench_l2.log 2>&1 || true
 echo l2 done >> $OUT/progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sweep -- python3 $ROOT/tools/sweep_bench.py > $OUT/sweep.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sweep -- python3 $ROOT/tools/sweep_bench.py --lanes 1 > $OUT/sweep.log 2>&1 || true
 echo sweep done >> $OUT/progress.log
 tail -1 $OUT/bench_trace.log | cut -c1-300
 grep "grid points" $OUT/sweep.log || true

@@ -16,12 +16,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--zones", type=int, default=4096)
 ap.add_argument("--cpz", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--contexts", type=int, default=2)
 ap.add_argument("--travel", action="store_true", help="tables from a synthetic Melbourne-shaped datamatrix, travel times on (the sweep's resample)")
 a = ap.parse_args()
 Z, T = a.zones, 24
 dev = torch.device("cuda:0")
 ctx, streams, bufs = [], [], []
-for i in range(2):
+for i in range(a.contexts):
     st = torch.cuda.Stream(device=dev)
     s = cpm.Sampler(Z, T, 0, stream=st)
     if a.travel:
@@ -55,7 +56,8 @@ def run(which, steps):
 
 for _ in range(2):
     one = run([0], a.steps)
-    other = run([1], a.steps)
-    both = run([0, 1], a.steps)
-    print(f"context 0 alone {one:.3f} ms per resample, context 1 alone {other:.3f}; both streams together {both:.3f} ms per pair "
-          f"({both / (one + other):.2f} of the sum)")
+    line = f"context 0 alone {one:.3f} ms per resample"
+    for n in range(2, a.contexts + 1):
+        t = run(list(range(n)), a.steps)
+        line += f"; {n} streams together {t:.3f} ms per round = {t / n:.3f} ms per resample ({t / (n * one):.2f} of one after the other)"
+    print(line)
