@@ -234,6 +234,19 @@ struct GroupedArgs {
 // memory round trip in front of every barrier that follows a ticket or a store, although only LDS contents change hands there.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Votes on a condition that already is a lane mask: HIP's __ballot / __any take an int, and hipcc materialises the mask as 0 / 1 in
+// a VGPR and compares it again (two VALU instructions per vote; the sampler is bound by what it issues).
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// p[i] = v with the address as uniform base + 32-bit BYTE offset (i x 4 B < 2^32: a bucket region): the store takes the base from
+// scalar registers and one VGPR instead of a 64-bit address pair built per store
+__device__ __forceinline__ void put32(uint32_t *p, uint32_t i, uint32_t v)
+{
+    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p) + (i << 2)) = v;
+}
+// lane 0's value to the whole wave (every lane active): one v_readfirstlane instead of the LDS crossbar of __shfl
+__device__ __forceinline__ uint32_t from_lane0(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 
@@ -249,7 +262,8 @@ __device__ __forceinline__ void pack_dma(uint32_t *lds, const uint32_t *pack, in
 #pragma unroll
     for (int m = 0; m < NQ; ++m) {
         const int p0 = min((m * (BLOCK / 64) + wave) * 64, pieces - 64);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4 *>(pack) + p0 + lane,
+        // (uniform base + 32-bit byte offset: the load takes the base from scalar registers and one VGPR, no 64-bit add per piece)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(pack) + (static_cast<uint32_t>(p0 + lane) << 4),
                                          (__attribute__((address_space(3))) void *)(lds + 4 * p0), 16, 0, 0);
     }
 }
@@ -302,13 +316,14 @@ __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint3
         n[c] = guide[m + 1];
     }
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
+    for (int c = 0; c < CPT; ++c) {  // (masked: a draw that does not search sits in bracket 0, whose width would join the wave's vote on K
+                                     //  -- leaving the select out cost 0.9 us per launch, half the lanes hold a stayer)
         n[c] = in[c] ? n[c] - lo[c] : 0u;
         nor |= n[c];
     }
-    if (__builtin_expect(__any(nor >= 32u), 0)) {  // wave-uniform
+    if (__builtin_expect(any64(nor >= 32u), 0)) {  // wave-uniform
         int K = 6;
-        while (__any((nor >> K) != 0u)) ++K;
+        while (any64((nor >> K) != 0u)) ++K;
         for (uint32_t s = 1u << (K - 1); s != 0u; s >>= 1) {
             uint32_t v[CPT];
 #pragma unroll
@@ -332,8 +347,8 @@ __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint3
         _Pragma("unroll") for (int c = 0; c < CPT; ++c) v_[c] = p[c][(S) - 1];              \
         _Pragma("unroll") for (int c = 0; c < CPT; ++c) p[c] += (v_[c] < kk[c]) ? (S) : 0;  \
     } while (0)
-    const bool a16 = __any(nor >= 16u);
-    const bool a8 = a16 || __any(nor >= 8u);
+    const bool a16 = any64(nor >= 16u);
+    const bool a8 = a16 || any64(nor >= 8u);
     if (a16) CPM_PACK_STEP(16);
     if (a8) CPM_PACK_STEP(8);
     CPM_PACK_STEP(4);
@@ -455,8 +470,9 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     uint32_t id[CPT + 1];
 #pragma unroll
     for (int c = 0; c <= CPT; ++c) {
-        const uint32_t *src = a.ids + b + min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(id[c]) : "v"(src) : "memory");
+        // (the bucket's base in scalar registers + a 32-bit byte offset: cap x 4 B < 2^32)
+        const uint32_t off = min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1) << 2;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(id[c]) : "v"(off), "s"(a.ids + b) : "memory");
     }
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
@@ -524,7 +540,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
             dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
             anyx |= want[c] & !ok[c];
         }
-        if (__builtin_expect(__any(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
+        if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
                 if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
@@ -537,19 +553,19 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         uint32_t total = 0;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            mS[c] = __ballot(valid[c] & !drive[c]);
+            mS[c] = ballot64(valid[c] & !drive[c]);
             total += static_cast<uint32_t>(__popcll(mS[c]));
         }
         uint32_t bS = 0;
         if (lane == 0 && total) bS = atomicAdd(&s_nstay, total);
-        bS = __shfl(bS, 0, 64);
+        bS = from_lane0(bS);
         // drivers: CPT rank atomics in flight together
         uint32_t rank[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            if (valid[c] & !drive[c]) stay_out[bS + static_cast<uint32_t>(__popcll(mS[c] & below))] = id[c];
+            if (valid[c] & !drive[c]) put32(stay_out, bS + static_cast<uint32_t>(__popcll(mS[c] & below)), id[c]);
             bS += static_cast<uint32_t>(__popcll(mS[c]));
         }
 #pragma unroll
@@ -584,10 +600,10 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         if (!want1[0]) dest1[0] = z;
         else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
         if (GROUPED) {
-            const unsigned long long m1 = __ballot(valid1 & !drive1);
+            const unsigned long long m1 = ballot64(valid1 & !drive1);
             uint32_t b1 = 0;
             if (lane == 0 && m1) b1 = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(m1)));
-            b1 = __shfl(b1, 0, 64);
+            b1 = from_lane0(b1);
             if (valid1 & !drive1) stay_out[b1 + static_cast<uint32_t>(__popcll(m1 & below))] = idx;
             if (drive1) {
                 const uint32_t g = dest1[0] >> a.gshift;
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
             anyx |= want[c] & !ok[c];
         }
-        if (__builtin_expect(__any(anyx), 0)) {
+        if (__builtin_expect(any64(anyx), 0)) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
                 if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
@@ -701,7 +717,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         uint32_t total = 0;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            mS[c] = __ballot(valid[c] & !drive[c]);
+            mS[c] = ballot64(valid[c] & !drive[c]);
             total += static_cast<uint32_t>(__popcll(mS[c]));
         }
         uint32_t bS = 0;
@@ -709,7 +725,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             bS = atomicAdd(&a.cnt_next[z], total);
             if (bS + total > cap) atomicOr(a.status, 2ull);
         }
-        bS = __shfl(bS, 0, 64);
+        bS = from_lane0(bS);
         uint32_t rank[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {

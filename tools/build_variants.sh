@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../carparkingmaps_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $flags -shared -o libcpm_hip_$name.so cpm_api.hip &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None $flags -shared -o libcpm_hip_$name.so cpm_api.hip &
 done
 wait
 ls -la libcpm_hip_*.so
