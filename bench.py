@@ -193,9 +193,9 @@ def main():
         barrier()
     if kernel_used == 0:
         kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
-    # hipEvents on the launch stream around every 25th hourly sampler launch of the timed region (25 is
-    # coprime to 24, so every hour of the day is sampled).  Bracketing every launch was measured to put
-    # two ~5 us bubbles around each of them: 12 % of the step; every 25th costs the step 0.5 %.
+    # Every 25th hourly sampler launch of the timed region carries a hipEvent pair (25 is coprime to 24, so every hour of the
+    # day is sampled): the library hands the pair to the launch itself (hipExtLaunchKernelGGL: begin and end of the dispatch),
+    # which sits ~1 us above rocprofv3's kernel duration; hipEventRecord on either side of a launch sat ~3 us above it.
     s.set_profile(True, stride=25, kernel=0)
     barrier()
     t0 = time.perf_counter()

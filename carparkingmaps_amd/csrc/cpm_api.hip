@@ -268,7 +268,7 @@ void prof_begin(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
     if (what != c->prof_what) return;
     c->prof_open = false;
     if (!c->profile || c->n_prof >= kMaxProf) return;
-    if ((c->prof_seen++ % c->prof_stride) != 0) return;  // an event pair costs ~2 x 5 us of stream bubbles: sample
+    if ((c->prof_seen++ % c->prof_stride) != 0) return;  // every prof_stride-th launch of the kind
     c->prof_open = true;
     size_t k = static_cast<size_t>(c->n_prof) * 2;
     while (c->ev.size() < k + 2) {
@@ -276,16 +276,17 @@ void prof_begin(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
         if (hipEventCreate(&e) != hipSuccess) return;
         c->ev.push_back(e);
     }
-    (void)hipEventRecord(c->ev[k], c->stream);
+    cpm::launch_timer() = cpm::LaunchTimer{c->ev[k], c->ev[k + 1]};  // carried by the launch that follows (cpm::launch)
 }
 
 void prof_end(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
 {
     if (what != c->prof_what || !c->prof_open) return;
     c->prof_open = false;
-    size_t k = static_cast<size_t>(c->n_prof) * 2;
-    if (c->ev.size() < k + 2) return;
-    (void)hipEventRecord(c->ev[k + 1], c->stream);
+    if (cpm::launch_timer().start) {  // no timed launch took the pair
+        cpm::launch_timer() = cpm::LaunchTimer{};
+        return;
+    }
     c->n_prof++;
 }
 
@@ -297,10 +298,10 @@ int32_t launch_step_car(cpm_ctx *c, const uint32_t *zin, uint32_t *out, int t, u
     const double *cdf = c->d_cdf + static_cast<size_t>(t) * c->Z * c->Zp;
     dim3 grid(nblk(c->n, 256)), block(256);
     if (travel)
-        hipLaunchKernelGGL(cpm::k_step_car<true>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
+        cpm::launch(cpm::k_step_car<true>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
                            c->Zp, c->n, c->cars, step, seed, c->d_dm, static_cast<int>(c->T), t, tt_sum);
     else
-        hipLaunchKernelGGL(cpm::k_step_car<false>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
+        cpm::launch(cpm::k_step_car<false>, grid, block, 0, c->stream, zin, out, pd, cdf, static_cast<int>(c->Z),
                            c->Zp, c->n, c->cars, step, seed, nullptr, static_cast<int>(c->T), t, nullptr);
     HIP_TRY(hipGetLastError());
     return CPM_OK;

@@ -434,7 +434,7 @@ inline void exact_launch_np(hipStream_t stream, size_t lds_tree, const uint32_t 
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_exact_sample<TRAVEL, 512, NP, 2>), dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, cdf, Z, Zp, H, cars, step,
+    launch(k_exact_sample<TRAVEL, 512, NP, 2>, dim3(Z), dim3(512), lds_tree, stream, ids, off, dest_out, pd, cdf, Z, Zp, H, cars, step,
                        seed, parking_t, driving_t, dm, T, t, tt_sum);
 }
 

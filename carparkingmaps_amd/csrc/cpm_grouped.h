@@ -993,7 +993,7 @@ inline void grouped_launch_place_t(hipStream_t stream, int bpg, const uint32_t *
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_place<PB, KRUNS, 2>), dim3(kGroups * bpg), dim3(PB), lds, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
+    launch(k_grouped_place<PB, KRUNS, 2>, dim3(kGroups * bpg), dim3(PB), lds, stream, D, cntg, zpg, zps, Z, cap, scap, idbits, cnt_next,
                        ids_next, status);
 }
 
@@ -1154,7 +1154,7 @@ inline void grouped_launch_nq(const GroupedArgs &a, size_t lds, hipStream_t stre
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>), dim3(a.Z), dim3(kSampleBlock), lds, stream, a);
+    launch(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>, dim3(a.Z), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <bool GROUPED, int CPT>
@@ -1514,7 +1514,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.cars = cars;
             tr.seed = seed;
             prof_begin(CPM_PROFILE_TRAVEL);
-            hipLaunchKernelGGL(k_grouped_travel, dim3(Z, 1), dim3(256), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
+            launch(k_grouped_travel, dim3(Z, 1), dim3(256), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             prof_end(CPM_PROFILE_TRAVEL);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
@@ -1531,7 +1531,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         tr.cars = cars;
         tr.seed = seed;
         prof_begin(CPM_PROFILE_TRAVEL);
-        hipLaunchKernelGGL(k_grouped_travel, dim3(Z, T), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        launch(k_grouped_travel, dim3(Z, T), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
         prof_end(CPM_PROFILE_TRAVEL);
     }
     if (travel && !ivp) {  // the partial sums of k_grouped_travel -> the sum word of the count tensor

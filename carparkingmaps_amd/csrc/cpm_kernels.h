@@ -11,11 +11,36 @@
 // Zone ids are 0-based on the device and 1-based on the host side of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "cpm_rng.h"
 
 namespace cpm {
+
+// Launch of an hourly kernel that may be timed (CPM_OPT_PROFILE): when the context has armed an event pair for the next launch, the
+// launch carries it (hipExtLaunchKernelGGL stamps the pair with the dispatch's own begin and end).  hipEventRecord on either side of a
+// launch instead times two extra barrier packets with it: ~3 us on a 26 us launch, and a bubble in the stream for each.
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+inline LaunchTimer &launch_timer()
+{
+    static thread_local LaunchTimer t;
+    return t;
+}
+template <typename... P, typename... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "one argument per kernel parameter");
+    LaunchTimer &t = launch_timer();
+    if (t.start) {  // (the extended launch copies its arguments as they are: converted to the kernel's own parameter types here)
+        hipExtLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds), stream, t.start, t.stop, 0, static_cast<P>(args)...);
+        t = LaunchTimer{};
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds), stream, static_cast<P>(args)...);
+    }
+}
 
 constexpr uint32_t kDriveBit = 0x80000000u;
 constexpr uint32_t kZoneMask = 0x7fffffffu;

@@ -65,8 +65,8 @@ extern "C" {
                                    * staged by LDS-DMA, stayers kept by the sampler, drivers placed per destination group; two launches per hour */
 
 #define CPM_OPT_KERNEL 1
-#define CPM_OPT_PROFILE 2       /* N >= 1: bracket every N-th hourly launch of the profiled kernel with hipEvents (an event
-                                   pair costs ~10 us of stream bubbles, so sample); 0: off */
+#define CPM_OPT_PROFILE 2       /* N >= 1: every N-th hourly launch of the profiled kernel carries a hipEvent pair stamped with the
+                                   dispatch's own begin and end (hipExtLaunchKernelGGL); 0: off */
 #define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
 #define CPM_PROFILE_SAMPLER 0   /*   the sampler (default; every kernel family has one) */
 #define CPM_PROFILE_PLACE 1     /*   the grouped path's placing kernel */
