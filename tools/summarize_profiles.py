@@ -72,7 +72,8 @@ if sweep:
     if os.path.exists(log):
         lines += [""] + ["    " + l.rstrip() for l in open(log) if "grid points" in l or "IVP" in l]
 head = os.popen(f"git -C {root} rev-parse --short HEAD 2>/dev/null").read().strip()
-lines.insert(1, f"(tree at {head or 'unknown commit'} + working changes; collected by tools/collect_profiles.sh)")
+dirty = os.popen(f"git -C {root} status --porcelain -- carparkingmaps_amd include bench.py tools 2>/dev/null").read().strip()
+lines.insert(1, f"(tree at {head or 'unknown commit'}{' + uncommitted changes to the sources' if dirty else ''}; collected by tools/collect_profiles.sh)")
 open(os.path.join(dst, f"{name}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(dst, f"{name}_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
