@@ -247,8 +247,7 @@ def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True, checksums=Fal
         prev = None
         for k, i in enumerate(pts):
             ev.begin(grid[i], k & 1)
-            if prev is not None:
-                yield prev[0], ev.finish(grid[prev[0]], prev[1])
+            yield (prev[0], ev.finish(grid[prev[0]], prev[1])) if prev is not None else None   # (None: the lane's first point is on its way)
             prev = (i, k & 1)
         if prev is not None:
             yield prev[0], ev.finish(grid[prev[0]], prev[1])
@@ -258,7 +257,9 @@ def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True, checksums=Fal
         while gens:
             for g in list(gens):
                 try:
-                    yield next(g)
+                    r = next(g)
+                    if r is not None:
+                        yield r
                 except StopIteration:
                     gens.remove(g)
 

@@ -135,3 +135,45 @@ def test_two_sampler_contexts_in_flight_give_the_same_points(cpm, O):
     for a, b in zip(one[:5], odd):
         assert all(a[k] == b[k] for k in keys)
     assert all(r["hours_hold_all_cars"] for r in two)
+
+
+def test_lanes_cover_the_ranks_slice_once_and_in_turn():
+    """grid_sweep's lane logic without a GPU: stub Evaluators that record the order of begin / finish."""
+    from carparkingmaps_amd import model_selection as ms
+
+    class Stub:
+        C = 10
+
+        def __init__(self, name, log):
+            self.name, self.log, self.open = name, log, {}
+
+        def begin(self, pt, slot):
+            assert slot not in self.open, "a slot is reused only after its finish"
+            self.open[slot] = pt
+            self.log.append((self.name, "begin", pt.e_drive))
+
+        def finish(self, pt, slot):
+            assert self.open.pop(slot) is pt
+            self.log.append((self.name, "finish", pt.e_drive))
+            z = np.full((3, 2), 5, dtype=np.int64)
+            return {"e_drive": pt.e_drive, "parking": z, "driving": z, "A_drive": 0.5}
+
+    grid = [ms.Point(float(i), 0.1, 0.9, 2 if i % 2 else 1) for i in range(11)]
+    for world in (1, 2):
+        for nl in (1, 2, 3):
+            got = {}
+            for rank in range(world):
+                log = []
+                lanes = [Stub(f"L{l}", log) for l in range(nl)]
+                res = ms.grid_sweep(lanes if nl > 1 else lanes[0], grid, rank=rank, world_size=world, gather=False)
+                mine = {i for i, r in enumerate(res) if r is not None}
+                assert not (mine & set(got)), "ranks share no point"
+                got.update({i: res[i] for i in mine})
+                begun = [e for (_, what, e) in log if what == "begin"]
+                assert sorted(begun) == sorted(grid[i].e_drive for i in mine) and len(set(begun)) == len(begun)
+                assert all(not l.open for l in lanes)
+                if nl > 1 and len(mine) >= 2 * nl:   # the lanes advance in turn: every lane has begun a point before any lane finishes one
+                    first_finish = next(k for k, (_, what, _) in enumerate(log) if what == "finish")
+                    assert {name for (name, what, _) in log[:first_finish]} == {l.name for l in lanes}
+            assert sorted(got) == list(range(len(grid)))
+            assert all(got[i]["e_drive"] == grid[i].e_drive and got[i]["hours_hold_all_cars"] is False for i in got)
