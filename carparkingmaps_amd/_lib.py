@@ -39,7 +39,7 @@ class CpmError(RuntimeError):
 
 def build(force=False):
     """Compile libcpm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(_HERE, "..", "include", "cpm.h"))
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
