@@ -193,10 +193,10 @@ def main():
         barrier()
     if kernel_used == 0:
         kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
-    # Every 25th hourly sampler launch of the timed region carries a hipEvent pair (25 is coprime to 24, so every hour of the
+    # Every 49th hourly sampler launch of the timed region carries a hipEvent pair (49 is coprime to 24, so every hour of the
     # day is sampled): the library hands the pair to the launch itself (hipExtLaunchKernelGGL: begin and end of the dispatch),
     # which sits ~1 us above rocprofv3's kernel duration; hipEventRecord on either side of a launch sat ~3 us above it.
-    s.set_profile(True, stride=25, kernel=0)
+    s.set_profile(True, stride=49, kernel=0)
     barrier()
     t0 = time.perf_counter()
     counts = run_steps(args.steps)

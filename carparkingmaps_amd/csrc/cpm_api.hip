@@ -349,10 +349,11 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         if (c->h_status[0] != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
         c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));
     }
-    HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
+    const int kernel = pick_kernel(c);
+    if (c->n == 0 || kernel != CPM_KERNEL_ZONE_GROUPED)  // (the grouped path zeroes the count tensor with its other counters, in one launch)
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nwords, c->stream));
     if (c->n == 0) return CPM_OK;
     unsigned long long *tt_sum = reinterpret_cast<unsigned long long *>(d_counts) + 2 * c->T * c->Z;
-    const int kernel = pick_kernel(c);
     if (kernel == CPM_KERNEL_ZONE_GROUPED) {
         if (!grouped_fits(c, c->zg.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR)");
@@ -413,7 +414,6 @@ int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
 int32_t ivp_grouped(cpm_ctx *c, uint64_t seed)
 {
     c->zx.buckets0_valid = false;  // the current state's grouped buckets may be cached (zg); everything else is stale once the IVP is committed
-    HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(int64_t) * static_cast<size_t>(2 * c->T * c->Z + 2), c->stream));
     int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, false, c->d_counts, c->cu_count,
                                   [](int) {}, [](int) {}, g_last_error, true, c->d_ztmp);
     if (rc != CPM_OK) return rc;

@@ -1407,6 +1407,21 @@ struct GroupedTables {
     int Z, Zp, Zq, T;
 };
 
+// Everything a run starts from zero, in ONE launch: the count tensor (driving counts, time sum and status word are added to),
+// the largest-bucket words and the per-hour heavy counts.  (Five hipMemsetAsync calls were five ~5 us fill kernels in the stream of
+// every resample, 2.5 % of it; the bucket sizes of the hours need no zeroing at all: the sampler stores every zone's stayers.)
+__global__ __launch_bounds__(256) void k_grouped_zero(unsigned long long *__restrict__ counts, size_t nwords, uint32_t *__restrict__ maxn,
+                                                      uint32_t *__restrict__ nheavy, int nh)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < nwords; i += stride) counts[i] = 0ull;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 2) maxn[threadIdx.x] = 0u;
+        for (int k = threadIdx.x; k < nh; k += 256) nheavy[k] = 0u;
+    }
+}
+
+// d_counts is zeroed here (k_grouped_zero), not by the caller.
 // ivp == false: the T-hour resample from the state in d_zone0 (left unchanged).  On overflow bit 1 of the status word
 //               (d_counts[2*T*Z+1]) is set and the counts are invalid.
 // ivp == true : solveinitialvalueproblem (src/solveinitialvalueproblem.jl:8,53): T-1 hours, steps 0..T-2, every transition
@@ -1435,10 +1450,12 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
     unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     unsigned long long *status = tt_sum + 1;
-    e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * static_cast<size_t>(T + 1) * Z, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(w.maxn, 0, 2 * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * (static_cast<size_t>(T) + 1), stream);
-    if (e != hipSuccess) return hip_fail(e, "memset counters");
+    {
+        const size_t nwords = 2 * static_cast<size_t>(T) * Z + 2;
+        const unsigned zgrid = static_cast<unsigned>(std::min<size_t>((nwords + 255) / 256, 1024));
+        hipLaunchKernelGGL(k_grouped_zero, dim3(zgrid), dim3(256), 0, stream, parking, nwords, w.maxn, w.nheavy, T + 1);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zeroing the counters");
+    }
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
         if ((e = hipMemsetAsync(w.cnt0, 0, sizeof(uint32_t) * Z, stream)) != hipSuccess) return hip_fail(e, "memset cnt0");
