@@ -900,10 +900,11 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
         HIP_TRY(hipGetLastError());
         c->pdrive_mean_valid = true;
     }
-    hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64)), dim3(64), 0, c->stream, c->d_pdrive_mean, c->d_pdrive,
-                       static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);
+    if (!c->d_thr) HIP_TRY(hipMalloc(&c->d_thr, sizeof(long long) * static_cast<size_t>(c->Z * c->T)));
+    hipLaunchKernelGGL(cpm::k_pdrive_final, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_pdrive_mean,
+                       c->d_pdrive, c->d_thr, static_cast<int>(c->Z), static_cast<int>(c->T), p_min, p_max, e_drive);  // (thresholds with it)
     hipError_t e = hipGetLastError();
-    int32_t rc_thr = (e == hipSuccess) ? update_thr(c) : CPM_OK;
+    int32_t rc_thr = CPM_OK;
     if (e == hipSuccess && out) {  // (without a host copy to wait for the call returns as soon as the kernels are enqueued: everything that
         e = hipMemcpyAsync(out, c->d_pdrive, bytes, hipMemcpyDeviceToHost, c->stream);  // uses the table follows on the same stream)
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

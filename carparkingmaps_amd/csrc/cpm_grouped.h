@@ -1013,6 +1013,14 @@ inline void grouped_launch_place(hipStream_t stream, const uint32_t *D, const ui
 // Travel times of an hour's drivers (src/resampling.jl:53-69), read back from the runs by a kernel of their own (inside the
 // sampler they cost it its occupancy: 138 VGPRs).  The sum is an integer in 2^-16 s units: order-free, bit-exact.
 constexpr int kTravelParts = 256;
+// Threads of the block of one (origin zone, hour): one wave while a lane has at most ~16 drivers (the ~500 drivers of a 1000-car zone
+// are two batches of four per lane; 256 threads made 4 x the waves for the same drivers -- 226 k per resample at Z = 2,357 -- and the
+// launch of waves was a third of the kernel: 349 us against 305), more for larger buckets, 256 once the context has seen heavy ones.
+inline int travel_block(int64_t mean_bucket, bool heavy_seen)
+{
+    if (heavy_seen || mean_bucket > 4096) return 256;
+    return mean_bucket > 2048 ? 128 : 64;
+}
 
 // The travel kernel gathers (mean, std) of its drivers' (origin, destination, hour) cells.  In the reference's datamatrix layout
 // [2][T][dest][origin] the two values lie Z*Z*T*8 B apart and consecutive destinations of one origin Z*8 B apart: two cache lines per
@@ -1052,7 +1060,7 @@ struct TravelArgs {
     uint64_t seed;
 };
 
-// one 256-thread block per (origin zone, hour).  When the runs of all hours of a resample are kept (GroupedWork::history) ONE launch
+// one block (travel_block threads) per (origin zone, hour).  When the runs of all hours of a resample are kept (GroupedWork::history) ONE launch
 // at the end serves them all: 24 x fewer launches and a grid 24 x as deep (at Z = 2,357 an hourly grid is 1.15 rounds of blocks).
 __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
                                                         uint32_t idbits, TravelArgs tr)
@@ -1531,7 +1539,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.cars = cars;
             tr.seed = seed;
             prof_begin(CPM_PROFILE_TRAVEL);
-            launch(k_grouped_travel, dim3(Z, 1), dim3(256), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
+            launch(k_grouped_travel, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             prof_end(CPM_PROFILE_TRAVEL);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
@@ -1548,7 +1556,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         tr.cars = cars;
         tr.seed = seed;
         prof_begin(CPM_PROFILE_TRAVEL);
-        launch(k_grouped_travel, dim3(Z, T), dim3(256), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        launch(k_grouped_travel, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
         prof_end(CPM_PROFILE_TRAVEL);
     }
     if (travel && !ivp) {  // the partial sums of k_grouped_travel -> the sum word of the count tensor

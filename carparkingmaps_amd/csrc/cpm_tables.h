@@ -87,23 +87,25 @@ __device__ __forceinline__ double pow_int(double x, long n)
     return yy;
 }
 
-// p_drive[i,t] = p_min + (p_max - p_min) * ((ms - min) / (max - min))^e_drive   (createpdrive.jl:22-33)
-__global__ void k_pdrive_final(const double *__restrict__ mean_sum, double *__restrict__ pdrive, int Z, int T,
+// p_drive[i,t] = p_min + (p_max - p_min) * ((ms - min) / (max - min))^e_drive   (createpdrive.jl:22-33), and the sampler's integer
+// threshold of it (thr may be null).  One thread per (zone, hour): each finds the zone's extrema over the day itself (24 L2-resident
+// loads) and raises ONE power -- a thread per zone walking the day did 24 pow_f64 one after the other, 19.6 us per grid point of a sweep.
+__global__ void k_pdrive_final(const double *__restrict__ mean_sum, double *__restrict__ pdrive, long long *__restrict__ thr, int Z, int T,
                                double p_min, double p_max, double e_drive)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
     if (i >= Z) return;
     double mx = mean_sum[i], mn = mean_sum[i];
-    for (int t = 1; t < T; ++t) {
-        double v = mean_sum[i + static_cast<size_t>(t) * Z];
+    for (int h = 1; h < T; ++h) {
+        double v = mean_sum[i + static_cast<size_t>(h) * Z];
         mx = jl_max(mx, v);
         mn = jl_min(mn, v);
     }
-    for (int t = 0; t < T; ++t) {
-        double v = 0.0;
-        if (mx > 0) v = p_min + (p_max - p_min) * pow_f64((mean_sum[i + static_cast<size_t>(t) * Z] - mn) / (mx - mn), e_drive);
-        pdrive[i + static_cast<size_t>(t) * Z] = v;
-    }
+    double v = 0.0;
+    if (mx > 0) v = p_min + (p_max - p_min) * pow_f64((mean_sum[i + static_cast<size_t>(t) * Z] - mn) / (mx - mn), e_drive);
+    pdrive[i + static_cast<size_t>(t) * Z] = v;
+    if (thr) thr[i + static_cast<size_t>(t) * Z] = bernoulli_threshold(v);
 }
 
 // unnormalised p_dest[i,j,t] = ((m - min_t m) / (max_t m - min_t m))^e_dest   (createpdestin.jl:10-28)
