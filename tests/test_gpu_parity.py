@@ -131,6 +131,30 @@ def test_travel_time_sum_bit_exact(cpm, O, kernel):
     assert r["sum_tt_q16"] == ref["sum_tt_q16"]
 
 
+@pytest.mark.parametrize("cpz", [700, 2600, 4500])
+def test_travel_time_sum_for_every_block_size_of_the_travel_kernel(cpm, O, cpz):
+    """The grouped path's travel kernel runs one wave per (origin zone, hour) for mean buckets up to 2048 cars, 128 threads up to
+    4096 and 256 above (cpm::travel_block): the time sum is bit-exact in each, with and without the runs of all hours kept."""
+    Z, T = 24, 24
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED + 3, density=0.5)
+    p_drive = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5)
+    p_dest = O.createpdestin(dm, Z, T, 2)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(cpm.CPM_KERNEL_ZONE_GROUPED)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.set_datamatrix(dm, dist)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        r = s.resample(SIM_SEED, travel=True)
+        assert s.get_info(1) == cpm.CPM_KERNEL_ZONE_GROUPED
+    assert np.array_equal(r["parking"], ref["parking"])
+    assert np.array_equal(r["driving"], ref["driving"])
+    assert r["sum_tt_q16"] == ref["sum_tt_q16"]
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_edge_rows(cpm, O, kernel):
     """Zero rows (dest = origin, still counted as driving: Appendix A-8), p_drive 0 / 1 / NaN zones
