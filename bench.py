@@ -10,16 +10,25 @@ state already resident in HBM), through the zone x hour count tensor -- and, for
 the single RCCL all-reduce of that tensor (step k's all-reduce runs under step k+1's kernels; the
 timed region ends when the last one has finished).  Workload at N = 1: synthetic dense Z = 4,096 zones,
 1,000 cars/zone (BASELINE.json configs[2], the configuration the metric is quoted on).  For
-N > 1 the cars per GPU stay fixed (weak scaling): Z = 4,096, 1,000*N cars/zone, car g on rank g mod N.
+N > 1 `value` keeps the cars per GPU fixed (weak scaling): Z = 4,096, 1,000*N cars/zone, car g on rank g mod N;
+the same JSON line then also carries `strong` (the metric's own C = 4,096,000 dealt over the N ranks) and, at N = 8,
+`configs3` (BASELINE.json configs[3]: Z = 8,192 x 4,000 cars/zone).
 
 roofline: B = algorithmic HBM bytes of one hourly launch = rows + Z*8 (p_drive) + C_g*8 (4 B id in, 4 B out)
 + 2*Z*8 (counts), with the element size of the rows the kernel really streams.  `achieved` / `frac` are for the dominant
 kernel (the hourly sampler launch: B over its hipEvent duration); `whole_resample` is 8(d)'s own figure, T*B over the wall
 time of a step; `kernels` lists every hourly kernel of the step with its own bytes, duration and measured traffic.
+
+Records outside the headline (N = 1 only, each a few seconds): `table_build` (the one pass from p_destin to the samplers' row
+tables), `per_dataset` (main.jl:79-95 at Melbourne's shape: createpdrive + createpdestin + IVP + resample with travel times),
+`skewed` (the headline workload on peaky destination tables), `two_resamples_in_flight`, `full_pipeline`, `cpu_baseline`.
+`--zones 2357 --cars-per-zone 100 --melbourne` is BASELINE.json configs[0]'s shape (the reference's own CPU-runnable case):
+its cpu_baseline times the faithful restatement on the Melbourne-shaped sparse tables.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,31 +38,48 @@ sys.path.insert(0, ROOT)
 TABLE_SEED = 0x5EED7AB1E
 SIM_SEED = 0x5EEDCA125
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-PROFILE_TAG = "round2"  # profiles/<tag>_traffic.json: PMC run of this same command (tools/collect_profiles.sh)
+PROFILE_TAG = "round3"  # profiles/<tag>_traffic.json: PMC run of this same command (tools/collect_profiles.sh)
+T = 24
 
 
-def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
+def pack_row_words(Z):
+    """words of one row pack of the grouped path (cpm_grouped.h: pack_guide_bits / pack_zq / pack_row_words)"""
+    g = 3
+    while (1 << g) < Z:
+        g += 1
+    G = max(3, g - 2)
+    return max(256, (1 << G) // 2 + 4 + (Z + 62) // 32 * 32)
+
+
+def cpu_baseline(sampler, Z, n_cars, time_budget_s, melbourne):
     """The faithful three-pass restatement of src/resampling.jl (oracle, single thread) on a
     bounded sample: the first `n_cars` cars, 24 h, starting from their post-IVP zones; its counts
-    are checked against the HIP path on the same cars."""
+    are checked against the HIP path on the same cars.  melbourne: on the sparse Melbourne-shaped tables (the oracle's
+    createpdrive / createpdestin of its synthetic datamatrix), travel-time pass included (src/resampling.jl:53-78)."""
     import numpy as np
     from oracle import oracle as O
 
-    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
-    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)        # reference layout, Z*Z*T*8 bytes on the host
+    dm = dist = None
+    if melbourne:
+        dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED)   # (bit-identical to the device's generator: tests/test_gpu_parity.py)
+        p_drive = sampler.get_p_drive()                   # the tables the device built from it (createpdrive agrees with the oracle's to
+        p_dest = sampler.build_p_dest(2)                  # 4e-16, not bit for bit: the CPU leg runs on the SAME tables as the GPU)
+    else:
+        p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+        p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)        # reference layout, Z*Z*T*8 bytes on the host
     zones = sampler.get_state()[:n_cars].copy()
     # calibrate the sample to the time budget on a small slice first
     probe = min(256, n_cars)
     st, tr = O.initializestates(probe, 1, T)
     st[:, 0] = zones[:probe]
     t0 = time.perf_counter()
-    O.resampling(st, tr, probe, Z, p_drive, p_dest, None, None, SIM_SEED, car_offset=0)
+    O.resampling(st, tr, probe, Z, p_drive, p_dest, dm, dist, SIM_SEED, car_offset=0)
     per_car = (time.perf_counter() - t0) / probe
     n = int(max(probe, min(n_cars, time_budget_s / max(per_car, 1e-9))))
     st, tr = O.initializestates(n, 1, T)
     st[:, 0] = zones[:n]
     t0 = time.perf_counter()
-    O.resampling(st, tr, n, Z, p_drive, p_dest, None, None, SIM_SEED, car_offset=0)
+    O.resampling(st, tr, n, Z, p_drive, p_dest, dm, dist, SIM_SEED, car_offset=0)
     dt = time.perf_counter() - t0
     pk, dr, _ = O.histogram(Z, st, tr)
     # the same cars through the HIP path
@@ -61,8 +87,10 @@ def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
     full = sampler.get_state()
     sampler.init_states(C_total, cpz, 0, n)
     sampler.set_state(zones[:n])
-    r = sampler.resample(SIM_SEED)
+    r = sampler.resample(SIM_SEED, travel=melbourne)
     ok = bool(np.array_equal(r["parking"], pk.astype(np.int64)) and np.array_equal(r["driving"], dr.astype(np.int64)))
+    if melbourne:
+        ok = ok and r["sum_tt_q16"] == int(O.sum_travel_time_q16(tr))
     sampler.init_states(C_total, cpz, begin, count, car_stride=stride)
     sampler.set_state(full)
     # all-core best effort beside it (oracle fast twin: prebuilt CDF + binary search, OpenMP over cars)
@@ -73,8 +101,9 @@ def cpu_baseline(sampler, Z, T, n_cars, time_budget_s):
     dt_fast = time.perf_counter() - t0
     fast = {"value": nfast * T / dt_fast, "unit": "car-steps/s", "cores": O.max_threads(), "kind": "port",
             "sample": f"first {nfast} cars x {T} h, prebuilt CDF + binary search, OpenMP over cars, {dt_fast:.1f} s"}
+    tables = "Melbourne-shaped sparse tables (8.68 % of the datamatrix populated), travel-time pass included" if melbourne else "dense synthetic tables"
     return {"value": n * T / dt, "unit": "car-steps/s", "cores": 1, "kind": "port", "all_cores": fast,
-            "sample": f"first {n} cars x {T} h of the same workload (faithful three-pass restatement of "
+            "sample": f"first {n} cars x {T} h of the same workload, {tables} (faithful three-pass restatement of "
                       f"src/resampling.jl, strided p_dest row gather + sum + linear walk), {dt:.1f} s",
             "counts_match_gpu": ok}
 
@@ -96,7 +125,178 @@ def pmc_traffic(Z, cars_per_gpu, skew):
             out["sampler"] = v["hbm_bytes_per_launch"]
         elif "k_grouped_place" in k:
             out["place"] = v["hbm_bytes_per_launch"]
+        elif "k_build_rows<false, true>" in k or "k_build_rows<0, 1>" in k:
+            out["build_rows"] = v["hbm_bytes_per_launch"]
     return out, "profiles/" + PROFILE_TAG + "_traffic.json"
+
+
+class Job:
+    """One workload on this rank's GPU: tables resident, cars dealt, IVP done; `run_steps` enqueues pipelined resamples."""
+
+    def __init__(self, env, Z, cpz_total, kernel=0, skew=0, melbourne=False, travel=False):
+        import carparkingmaps_amd as cpm  # noqa: F401
+        from carparkingmaps_amd.distributed import ShardedSampler
+        self.env, self.Z, self.cpz, self.C, self.travel = env, Z, cpz_total, Z * cpz_total, travel
+        self.ss = ShardedSampler(Z, T, rank=env.rank, world_size=env.world, device=env.local_rank, deal=env.deal)
+        self.s = self.ss.s
+        self.s.set_kernel(kernel)
+        self.kernel = kernel
+        if melbourne:
+            self.s.synth_datamatrix(TABLE_SEED)
+            self.s.build_p_drive(0.1, 0.9, 0.5, want=False)
+            self.s.build_p_dest(2, want=False)
+        else:
+            self.s.synth_tables(TABLE_SEED, skew_q=skew)
+        self.first, self.count = self.ss.init_states(self.C, cpz_total)
+        self.s.solve_ivp_async(SIM_SEED)          # 23 untimed burn-in steps (main.jl:91-92)
+        self.s.sync()
+        if env.rehearse and env.world > 1:  # gloo cannot reduce device tensors: bounce through the host
+            import torch
+            import torch.distributed as dist
+            ss, s = self.ss, self.s
+
+            def resample_allreduce_async(seed, travel=False):
+                with torch.cuda.stream(ss.stream):
+                    s.resample_dev(seed, ss.counts.data_ptr(), travel=travel)
+                    host = ss.counts.cpu()
+                    dist.all_reduce(host)
+                    ss.counts.copy_(host)
+                return ss.counts, 0
+            ss.resample_allreduce_async = resample_allreduce_async
+            ss.wait = lambda ticket: None
+
+    def run_steps(self, k):
+        """k pipelined steps: the all-reduce of a step overlaps the kernels of the next one; returns the last count tensor"""
+        buf = None
+        for _ in range(k):
+            buf, _ = self.ss.resample_allreduce_async(SIM_SEED, travel=self.travel)
+        self.ss.synchronize()
+        return buf
+
+    def settle(self, warmup):
+        """Warm-up; the grouped kernels flag a bucket / run that outgrew its region in the status word (summed over ranks by the
+        all-reduce): the step is then invalid, the context doubles its regions when it next enqueues.  Returns the kernel in use."""
+        counts = self.run_steps(warmup)
+        self.env.barrier()
+        kernel_used = self.kernel
+        for _ in range(6):
+            if counts is None or int(counts[-1].item()) == 0:
+                break
+            counts = self.run_steps(max(warmup, 2))
+            self.env.barrier()
+        if counts is not None and int(counts[-1].item()) != 0:
+            kernel_used = 2
+            self.s.set_kernel(kernel_used)
+            counts = self.run_steps(max(warmup, 1))
+            self.env.barrier()
+        if kernel_used == 0:
+            kernel_used = {5: 0}.get(self.s.get_info(1), self.s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
+        self.kernel_used = kernel_used
+        return kernel_used
+
+    def timed(self, steps):
+        """wall time of `steps` steps bracketed by barrier + synchronize on both sides, MAX over ranks; the last count tensor"""
+        import torch
+        import torch.distributed as dist
+        env = self.env
+        env.barrier()
+        t0 = time.perf_counter()
+        counts = self.run_steps(steps)
+        env.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.rehearse else "cuda")
+        if env.world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), counts
+
+    def check(self, counts):
+        import carparkingmaps_amd as cpm
+        parking, driving, _ = cpm.distributed.split_counts(counts, self.Z, T)
+        assert (parking.sum(axis=0) == self.C).all(), "every hour must hold all C cars"
+        return parking, driving
+
+    def close(self):
+        self.ss.close()
+
+
+class Env:
+    pass
+
+
+def side_record(env, Z, cpz_total, steps, what, **kw):
+    """a secondary workload measured like the headline (settle, then `steps` timed steps): ms per resample and car-steps/s"""
+    job = Job(env, Z, cpz_total, **kw)
+    job.settle(3)
+    dt, counts = job.timed(steps)
+    parking, _ = job.check(counts)
+    ms = dt / steps * 1e3
+    rec = {"what": what, "zones": Z, "cars": job.C, "cars_per_gpu": job.count, "steps": steps, "ms_per_step": ms,
+           "value": job.C * T * steps / dt, "unit": "car-steps/s", "bucket_region_x_mean": job.s.get_info(2),
+           "largest_bucket_x_mean": float(parking.max()) / (job.C / Z),
+           "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 5: "zone_grouped"}[job.kernel_used]}
+    return rec, job
+
+
+def table_build_record(s, Z, traffic):
+    """The one pass from the resident p_destin (reference layout, f64) to what the samplers read (k_build_rows): row totals,
+    running-sum checkpoints, row packs -- and, in the second figure, the canonical f64 CDF rows the grouped path never reads."""
+    out = {}
+    rw = pack_row_words(Z)
+    nck = (Z + 31) // 32
+    for name, full in (("packs", False), ("packs_and_f64_cdf", True)):
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            s.refresh_tables(with_f64_cdf=full)          # blocking (the validation flag is read back)
+            ts.append(time.perf_counter() - t0)
+        ms = statistics.median(ts) * 1e3
+        nbytes = Z * Z * T * 8 + T * Z * rw * 4 + T * Z * 8 + T * nck * Z * 8 + (T * Z * ((Z + 15) // 16 * 16) * 8 if full else 0)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": traffic.get("build_rows") if not full else None}
+    s.refresh_tables(with_f64_cdf=False)
+    out["what"] = ("p_destin (Z x Z x T f64, reference layout) -> row packs (guide + CDF high words) + row totals + checkpoints in ONE "
+                   "launch (k_build_rows; sequential f64 running sum of src/resampling.jl:39); wall time of the blocking call, median of 5; "
+                   "round 2 took three launches for this (CDF, high words, guide): 3.77 ms at Z = 4,096")
+    return out
+
+
+def per_dataset_record(env):
+    """main.jl:79-95 for one dataset at Melbourne's shape (Z = 2,357, 1,000 cars/zone): the tables from the (synthetic, device-
+    generated) datamatrix, the 23-hour IVP, the 24-hour resample with travel times.  Every stage timed as a blocking call."""
+    import carparkingmaps_amd as cpm
+    Z, cpz = 2357, 1000
+    C = Z * cpz
+    s = cpm.Sampler(Z, T, env.local_rank)
+    s.synth_datamatrix(TABLE_SEED)
+
+    def once():
+        t0 = time.perf_counter()
+        s.build_p_drive(0.1, 0.9, 0.5, want=False)
+        s.sync()
+        t1 = time.perf_counter()
+        s.build_p_dest(2, want=False)
+        t2 = time.perf_counter()
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        t3 = time.perf_counter()
+        r = s.resample(SIM_SEED, travel=True)
+        t4 = time.perf_counter()
+        return (t1 - t0, t2 - t1, t3 - t2, t4 - t3), r
+    once()
+    runs = [once() for _ in range(3)]
+    med = [statistics.median(r[0][k] for r in runs) * 1e3 for k in range(4)]
+    r = runs[-1][1]
+    assert (r["parking"].sum(axis=0) == C).all()
+    s.close()
+    total = sum(med)
+    cells = Z * Z * T * 8
+    return {"what": "one dataset of main.jl:79-95 at Melbourne's shape (Z = 2,357 x 1,000 cars/zone, synthetic sparse datamatrix resident in "
+                    "HBM): createpdrive, createpdestin (weights, row sums, row tables), initializestates + 23-hour IVP, 24-hour resample "
+                    "with travel times and the count tensor on the host; blocking calls, median of 3",
+            "createpdrive_ms": med[0], "createpdestin_ms": med[1], "ivp_ms": med[2], "resample_ms": med[3], "total_ms": total,
+            "tables_algorithmic_bytes": int(cells + Z * Z * 8 + 3 * cells + cells + T * Z * pack_row_words(Z) * 4),
+            "value": C * (2 * T - 1) / (total * 1e-3), "unit": "car-steps/s"}
 
 
 def main():
@@ -110,113 +310,69 @@ def main():
     ap.add_argument("--deal", default="interleaved", choices=["interleaved", "contiguous"], help="how cars are dealt over the ranks")
     ap.add_argument("--skew", type=int, default=0, help="Q > 0: skewed destination popularity 1 / (Q + rank) (secondary figure; 32 ~ the "
                                                         "most popular zone 26x the mean); 0: the flat headline tables")
+    ap.add_argument("--melbourne", action="store_true", help="Melbourne-shaped sparse tables (synthetic datamatrix -> createpdrive / "
+                                                             "createpdestin on the device) and travel times instead of the dense synthetic tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair", action="store_true", help="skip the two-resamples-in-flight figure (profiling runs: its launches overlap, "
                                                            "which would blur the per-kernel statistics)")
+    ap.add_argument("--no-side", action="store_true", help="skip the secondary records (table_build, per_dataset, skewed, strong, configs3)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import carparkingmaps_amd as cpm
-    from carparkingmaps_amd.distributed import ShardedSampler
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env = Env()
+    env.rank = rank = int(os.environ.get("RANK", "0"))
+    env.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    env.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    env.deal = args.deal
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
     # CPM_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (every
     # rank on the visible devices round-robin, gloo instead of RCCL).  Never used for reported numbers.
-    rehearse = os.environ.get("CPM_BENCH_REHEARSE") == "1"
+    env.rehearse = rehearse = os.environ.get("CPM_BENCH_REHEARSE") == "1"
     if rehearse:
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        env.local_rank = env.local_rank % max(torch.cuda.device_count(), 1)
+    local_rank = env.local_rank
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    Z, T = args.zones, 24
-    cpz = args.cars_per_zone * world
-    C = Z * cpz
-    ss = ShardedSampler(Z, T, rank=rank, world_size=world, device=local_rank, deal=args.deal)
-    s = ss.s
-    s.set_kernel(args.kernel)
-    s.synth_tables(TABLE_SEED, skew_q=args.skew)
-    first, count = ss.init_states(C, cpz)
-    s.solve_ivp_async(SIM_SEED)          # 23 untimed burn-in steps (main.jl:91-92)
-    s.sync()
+        backend = dist.get_backend()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    env.barrier = barrier
 
-    if rehearse and world > 1:  # gloo cannot reduce device tensors: bounce through the host
-        def resample_allreduce_async(seed, travel=False):
-            with torch.cuda.stream(ss.stream):
-                s.resample_dev(seed, ss.counts.data_ptr())
-                host = ss.counts.cpu()
-                dist.all_reduce(host)
-                ss.counts.copy_(host)
-            return ss.counts, 0
-        ss.resample_allreduce_async = resample_allreduce_async
-        ss.wait = lambda ticket: None
-
-    def run_steps(k):
-        """k pipelined steps: the all-reduce of a step overlaps the kernels of the next one; returns the last count tensor"""
-        buf = None
-        for _ in range(k):
-            buf, _ = ss.resample_allreduce_async(SIM_SEED)
-        ss.synchronize()
-        return buf
-
-    counts = run_steps(args.warmup)
-    barrier()
-    # The grouped kernels flag a bucket / run that outgrew its region in the status word (summed over ranks by the
-    # all-reduce); the step is then invalid, the context doubles its regions when it next enqueues.
-    kernel_used = args.kernel
-    for _ in range(6):
-        if counts is None or int(counts[-1].item()) == 0:
-            break
-        counts = run_steps(max(args.warmup, 2))
-        barrier()
-    if counts is not None and int(counts[-1].item()) != 0:
-        kernel_used = 2
-        s.set_kernel(kernel_used)
-        counts = run_steps(max(args.warmup, 1))
-        barrier()
-    if kernel_used == 0:
-        kernel_used = {5: 0}.get(s.get_info(1), s.get_info(1))  # what AUTO resolved to (0 stands for its default, the grouped path)
+    Z = args.zones
+    cpz = args.cars_per_zone * world
+    job = Job(env, Z, cpz, kernel=args.kernel, skew=args.skew, melbourne=args.melbourne, travel=args.melbourne)
+    ss, s, C, count = job.ss, job.s, job.C, job.count
+    kernel_used = job.settle(args.warmup)
     # Every 49th hourly sampler launch of the timed region carries a hipEvent pair (49 is coprime to 24, so every hour of the
     # day is sampled): the library hands the pair to the launch itself (hipExtLaunchKernelGGL: begin and end of the dispatch),
     # which sits ~1 us above rocprofv3's kernel duration; hipEventRecord on either side of a launch sat ~3 us above it.
     s.set_profile(True, stride=49, kernel=0)
-    barrier()
-    t0 = time.perf_counter()
-    counts = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, counts = job.timed(args.steps)
     sampler_ms = s.last_kernel_ms()
     s.set_profile(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    parking, driving, _ = cpm.distributed.split_counts(counts, Z, T)
-    assert (parking.sum(axis=0) == C).all(), "every hour must hold all C cars"
+    parking, driving = job.check(counts)
 
     # the other hourly kernel of the step, timed the same way outside the headline's timed region
     place_ms = []
     if kernel_used in (0, 5):
         s.set_profile(True, stride=7, kernel=1)
-        run_steps(max(8, min(args.steps, 40)))
+        job.run_steps(max(8, min(args.steps, 40)))
         place_ms = s.last_kernel_ms()
         s.set_profile(False)
 
@@ -229,7 +385,7 @@ def main():
         ss.init_states(C, cpz)
         with torch.cuda.stream(ss.stream):
             s.solve_ivp_async(SIM_SEED)
-        ss.resample_allreduce(SIM_SEED)
+        ss.resample_allreduce(SIM_SEED, travel=job.travel)
     ss.synchronize()
     barrier()
     dt_full = (time.perf_counter() - t0) / reps
@@ -238,7 +394,7 @@ def main():
     # parameter sweep or a run over several seeds does).  The hours of ONE resample are a serial chain of an issue-bound sampler
     # launch and a latency-bound placing launch; two chains interleave on the chip.  Outside the headline's timed region.
     pair_ms = None
-    if world == 1 and kernel_used in (0, 5) and not args.no_pair:
+    if world == 1 and kernel_used in (0, 5) and not args.no_pair and not args.melbourne:
         st2 = torch.cuda.Stream(device=local_rank)
         s2 = cpm.Sampler(Z, T, local_rank, stream=st2)
         s2.set_kernel(args.kernel)
@@ -261,8 +417,29 @@ def main():
         assert same, "the second context must reproduce the first one's counts"
         s2.close()
 
+    side = {}
+    if not args.no_side and not args.skew and not args.melbourne and Z == 4096 and args.cars_per_zone == 1000:
+        if world == 1:
+            traffic0, _ = pmc_traffic(Z, count, args.skew)
+            side["table_build"] = table_build_record(s, Z, traffic0)
+            side["per_dataset"] = per_dataset_record(env)
+            rec, j2 = side_record(env, Z, cpz, 20, "the headline workload on skewed destination tables (popularity 1 / (32 + rank): the shape of real "
+                                  "Uber Movement rows, README.md output_24_0.svg); bucket regions grown by the context as needed", skew=32)
+            j2.close()
+            side["skewed"] = rec
+        else:
+            # what BASELINE.json asks of an N-GPU run beside the weak line: the metric's own fleet dealt over the ranks ...
+            rec, j2 = side_record(env, Z, 1000, 40, f"strong scaling: the metric's own configuration (Z = 4,096 x 1,000 cars/zone, C = 4,096,000) "
+                                  f"dealt over {world} ranks; every rank streams the whole table each hour, so this form is table-bound by design")
+            j2.close()
+            side["strong"] = rec
+            if world == 8:  # ... and configs[3]
+                rec, j2 = side_record(env, 8192, 4000, 10, "BASELINE.json configs[3]: Z = 8,192 x 4,000 cars/zone (C = 32,768,000) sharded by car over 8 ranks, "
+                                      "one all-reduce of the zone x hour counts per step")
+                j2.close()
+                side["configs3"] = rec
+
     if rank == 0:
-        import numpy as np
         car_steps = C * T
         ms_per_step = dt / args.steps * 1e3
         alg_bytes = s.algorithmic_bytes_per_hour()
@@ -286,6 +463,8 @@ def main():
         if place_ms:
             kernels.append(kernel_entry("k_grouped_place", "drivers from the runs into next hour's buckets (not part of 8(d)'s compulsory bytes: "
                                         "its ids are counted with the sampler's C_g*8)", place_bytes, place_avg, len(place_ms), traffic.get("place")))
+        tables = (f"Melbourne-shaped sparse tables (synthetic datamatrix, createpdrive / createpdestin on the device), travel times on" if args.melbourne
+                  else f"synthetic {'skewed (destination popularity 1/(%d+rank))' % args.skew if args.skew else 'dense'} p_dest")
         out = {
             "metric": "car-steps/sec at Z=4,096, 1k cars/zone; 1/2/4/8 MI355X + %HBM roofline",
             "value": car_steps * args.steps / dt,
@@ -300,7 +479,9 @@ def main():
             "dtype": "f64",  # the contract's arithmetic (f64 CDF compare, 53-bit draws); the default kernel evaluates it on 32-bit high words
                              # and 64-bit integers with an exact f64 fallback, bit-identical by construction
             "data": "synthetic" + (" (REHEARSAL: gloo, shared GPU -- not a measurement)" if rehearse else ""),
-            "config": {"workload": f"synthetic {'skewed (destination popularity 1/(%d+rank))' % args.skew if args.skew else 'dense'} p_dest, Z={Z} zones, "
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": backend,
+            "config": {"workload": f"{tables}, Z={Z} zones, "
                                    f"{cpz} cars/zone (C={C}), T={T} h resample from the post-IVP state; {args.cars_per_zone} cars/zone per GPU",
                        "zones": Z, "cars": C, "cars_per_gpu": count, "hours": T,
                        "kernel": {0: "auto (zone_grouped)", 1: "car", 2: "zone_lds", 5: "zone_grouped"}[kernel_used]
@@ -327,6 +508,7 @@ def main():
             "full_pipeline": {"value": C * (2 * T - 1) / dt_full, "unit": "car-steps/s", "ms": dt_full * 1e3,
                               "what": "initializestates + 23-hour IVP + 24-hour resample (main.jl:88-95), 47 car-steps per car"},
         }
+        out.update(side)
         if pair_ms is not None:
             out["two_resamples_in_flight"] = {
                 "what": "two contexts, two streams, the same fleet and tables: wall time per PAIR of resamples; not the headline (value "
@@ -334,9 +516,9 @@ def main():
                 "value": 2 * car_steps / (pair_ms * 1e-3), "unit": "car-steps/s",
                 "whole_resample_frac": 2 * T * alg_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline and not args.skew:
-            out["cpu_baseline"] = cpu_baseline(s, Z, T, min(count, 65536), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(s, Z, min(count, 65536), args.cpu_seconds, args.melbourne)
         print(json.dumps(out), flush=True)
-    ss.close()
+    job.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "cpm_solve_ivp_async", "cpm_synth_tables", "cpm_last_kernel_ms", "cpm_algorithmic_bytes_per_hour",
     "cpm_debug_categorical", "cpm_createdatamatrix_rows", "cpm_createdatamatrix_csv", "cpm_get_datamatrix",
     "cpm_set_distance_from_centroids", "cpm_get_distance", "cpm_parse_uber_csv", "cpm_set_distance", "cpm_get_info",
-    "cpm_init_states_strided", "cpm_synth_tables_skewed",
+    "cpm_init_states_strided", "cpm_synth_tables_skewed", "cpm_synth_datamatrix", "cpm_refresh_tables",
 ]
 
 CPM_FLAG_TRAVEL = 1
@@ -94,6 +94,8 @@ def load():
     L.cpm_solve_ivp_async.argtypes = [vp, u64]
     L.cpm_synth_tables.argtypes = [vp, u64]
     L.cpm_synth_tables_skewed.argtypes = [vp, u64, i64]
+    L.cpm_synth_datamatrix.argtypes = [vp, u64, dbl]
+    L.cpm_refresh_tables.argtypes = [vp, i32]
     L.cpm_last_kernel_ms.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.cpm_algorithmic_bytes_per_hour.argtypes = [vp, C.POINTER(i64)]
     L.cpm_debug_categorical.argtypes = [vp, i64, i64, i64, vp, vp, C.POINTER(i32)]

@@ -72,10 +72,16 @@ struct cpm_ctx {
     bool have_stream = false;
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
-    double *d_cdf = nullptr;     // [T][Z][Zp]
-    double *d_pdest_work = nullptr;  // [T][Z][Z] reference layout: cpm_build_p_dest's p_destin before it becomes the CDF
+    double *d_p = nullptr;       // [T][Z dest][Z origin] p_destin as the reference lays it out (cpm_set_p_dest, the synthetic tables), or
+                                 // createpdestin's unnormalised weights with their row sums in d_nf (cpm_build_p_dest).  Resident: the row
+                                 // tables below are derived from it in one pass (k_build_rows), ties walk it (search_exact_ckpt)
+    double *d_nf = nullptr;      // [T][Z] row sums of d_p while have_nf (an entry is then d_p / d_nf where d_nf > 0)
+    bool have_nf = false;
+    double *d_cdf = nullptr;     // [T][Z][Zp] canonical f64 CDF rows: built on first need (ensure_full_cdf) -- the car and exact-layout
+    bool cdf_full = false;       // kernels and cpm_get_cdf_row read them, the grouped path never does
     uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_grouped.h)
     double *d_last = nullptr;    // [T][Z] row totals
+    double *d_ckpt = nullptr;    // [T][nck][Z] every 32nd value of the running sums (exact fallback of the grouped path)
     long long *d_thr = nullptr;  // [T][Z] Bernoulli thresholds of p_drive (k_build_thr), rebuilt whenever p_drive changes
     int Zq = 0;
     double *d_dm = nullptr;      // [2][T][Z][Z] (reference layout)
@@ -186,40 +192,72 @@ int32_t update_thr(cpm_ctx *c)
     return CPM_OK;
 }
 
-// p (device, reference layout Z x Z x T) -> canonical CDF
-int32_t build_cdf_from_device(cpm_ctx *c, const double *d_p)
+template <bool CDF, bool PACK>
+hipError_t launch_build_rows(cpm_ctx *c)
 {
-    size_t cdf_elems = static_cast<size_t>(c->T) * c->Z * c->Zp;
-    if (!c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * cdf_elems));
-    dim3 grid(nblk(c->Z, cpm::kCdfTile), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL(cpm::k_build_cdf, grid, dim3(cpm::kCdfTile), 0, c->stream, d_p, c->d_cdf,
-                       static_cast<int>(c->Z), c->Zp, c->d_err);
-    HIP_TRY(hipGetLastError());
-    c->have_cdf = false;
-    int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)",
-                                CPM_ERR_TABLE);
-    if (rc != CPM_OK) return rc;
-    if (cpm::pack_row_fits(static_cast<int>(c->Z))) {  // the row packs (guide + high words) of the grouped zone path
-        const int64_t rows = c->T * c->Z;
-        const int G = cpm::pack_guide_bits(static_cast<int>(c->Z));
-        const size_t words = static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, G);
-        if (!c->d_hi) HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * words));
-        if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
-        const unsigned gy = static_cast<unsigned>(std::min<int64_t>(rows, 32768)), gz = static_cast<unsigned>((rows + gy - 1) / gy);
-        hipLaunchKernelGGL(cpm::k_build_hi32, dim3(nblk(c->Zq, 256), gy, gz), dim3(256), 0, c->stream, c->d_cdf, c->d_hi, c->d_last,
-                           static_cast<int>(c->Z), c->Zp, c->Zq, G, rows);
-        hipLaunchKernelGGL(cpm::k_build_guide, dim3(nblk((int64_t(1) << G) + 8, 256), gy, gz), dim3(256), 0, c->stream, c->d_hi,
-                           static_cast<int>(c->Z), c->Zq, G, rows);
-        HIP_TRY(hipGetLastError());
+    static bool attr_done[64] = {};  // LDS opt-in (two 64 x 65 f64 tiles), once per device and instantiation
+    if (c->device < 0 || c->device >= 64 || !attr_done[c->device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_build_rows<CDF, PACK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(cpm::kRowLds));
+        if (e != hipSuccess) return e;
+        if (c->device >= 0 && c->device < 64) attr_done[c->device] = true;
     }
+    dim3 grid(nblk(c->Z, cpm::kRowTile), static_cast<unsigned>(c->T));
+    hipLaunchKernelGGL((cpm::k_build_rows<CDF, PACK>), grid, dim3(cpm::kRowBlock), cpm::kRowLds, c->stream, c->d_p, c->have_nf ? c->d_nf : nullptr,
+                       CDF ? c->d_cdf : nullptr, PACK ? c->d_hi : nullptr, c->d_last, c->d_ckpt, static_cast<int>(c->Z), c->Zp, c->Zq,
+                       cpm::pack_guide_bits(static_cast<int>(c->Z)), c->d_err);
+    return hipGetLastError();
+}
+
+// The table in d_p (+ d_nf) -> everything the samplers read: row totals, checkpoints and -- when a row pack fits LDS -- the row packs
+// of the grouped path, in one pass.  The f64 CDF rows are built with them only when no pack fits (then every kernel searches f64
+// rows) or when the caller asks; otherwise on first need (ensure_full_cdf).
+int32_t build_rows(cpm_ctx *c, bool with_cdf)
+{
+    const int64_t rows = c->T * c->Z;
+    const bool pack = cpm::pack_row_fits(static_cast<int>(c->Z));
+    const bool cdf = with_cdf || !pack;
+    c->have_cdf = false;
+    c->cdf_full = false;
+    if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
+    if (!c->d_ckpt) HIP_TRY(hipMalloc(&c->d_ckpt, sizeof(double) * static_cast<size_t>(rows) * cpm::ckpt_count(static_cast<int>(c->Z))));
+    if (pack && !c->d_hi)
+        HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))));
+    if (cdf && !c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * static_cast<size_t>(rows) * c->Zp));
+    hipError_t e_rows;
+    if (cdf && pack) e_rows = launch_build_rows<true, true>(c);
+    else if (cdf) e_rows = launch_build_rows<true, false>(c);
+    else e_rows = launch_build_rows<false, true>(c);
+    HIP_TRY(e_rows);
+    int32_t rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)", CPM_ERR_TABLE);
+    if (rc != CPM_OK) return rc;
     c->have_cdf = true;
+    c->cdf_full = cdf;
+    c->zx.tables_dirty = true;
+    return CPM_OK;
+}
+
+// the canonical f64 CDF rows of the installed table, for the kernels that search them (enqueued on the context's stream)
+int32_t ensure_full_cdf(cpm_ctx *c)
+{
+    if (c->cdf_full) return CPM_OK;
+    if (!c->have_cdf) return fail(CPM_ERR_STATE, "p_dest not set");
+    if (!c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * static_cast<size_t>(c->T * c->Z) * c->Zp));
+    double *keep_last = c->d_last, *keep_ckpt = c->d_ckpt;  // (already built: this pass writes the CDF rows only)
+    c->d_last = nullptr;
+    c->d_ckpt = nullptr;
+    hipError_t e = launch_build_rows<true, false>(c);
+    c->d_last = keep_last;
+    c->d_ckpt = keep_ckpt;
+    HIP_TRY(e);
+    c->cdf_full = true;
     c->zx.tables_dirty = true;
     return CPM_OK;
 }
 
 bool grouped_fits(const cpm_ctx *c, int cap_mult)
 {
-    return c->d_hi && c->d_last && c->d_thr && cpm::grouped_path_fits(c->n, static_cast<int>(c->Z), cap_mult);
+    return c->d_hi && c->d_last && c->d_ckpt && c->d_thr && cpm::grouped_path_fits(c->n, static_cast<int>(c->Z), cap_mult);
 }
 
 // AUTO: a zone-bucketed LDS path when a row fits in LDS and there are enough cars per zone to amortise streaming every row once
@@ -252,7 +290,9 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
     tb.rp = c->d_hi;
     tb.last = c->d_last;
     tb.thr = c->d_thr;
-    tb.cdf = c->d_cdf;
+    tb.ckpt = c->d_ckpt;
+    tb.p = c->d_p;
+    tb.nf = c->have_nf ? c->d_nf : nullptr;
     tb.tt = c->d_tt;
     tb.Z = static_cast<int>(c->Z);
     tb.Zp = c->Zp;
@@ -269,25 +309,23 @@ void prof_begin(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
     c->prof_open = false;
     if (!c->profile || c->n_prof >= kMaxProf) return;
     if ((c->prof_seen++ % c->prof_stride) != 0) return;  // every prof_stride-th launch of the kind
-    c->prof_open = true;
     size_t k = static_cast<size_t>(c->n_prof) * 2;
     while (c->ev.size() < k + 2) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventCreate(&e) != hipSuccess) return;  // (no pair: this launch is not timed, nothing is counted)
         c->ev.push_back(e);
     }
     cpm::launch_timer() = cpm::LaunchTimer{c->ev[k], c->ev[k + 1]};  // carried by the launch that follows (cpm::launch)
+    c->prof_open = true;                                               // only now: the pair exists and the timer is armed
 }
 
 void prof_end(cpm_ctx *c, int what = CPM_PROFILE_SAMPLER)
 {
     if (what != c->prof_what || !c->prof_open) return;
     c->prof_open = false;
-    if (cpm::launch_timer().start) {  // no timed launch took the pair
-        cpm::launch_timer() = cpm::LaunchTimer{};
-        return;
-    }
-    c->n_prof++;
+    const bool taken = cpm::launch_timer().start == nullptr;  // cpm::launch clears the timer when it hands the pair to a dispatch
+    cpm::launch_timer() = cpm::LaunchTimer{};
+    if (taken) c->n_prof++;  // a pair no launch stamped is reused by the next timed launch, never read
 }
 
 // one hourly step of the one-thread-per-car kernel
@@ -376,6 +414,10 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
         }
         return rc;
     }
+    {   // these kernels search the f64 CDF rows
+        int32_t rc_cdf = ensure_full_cdf(c);
+        if (rc_cdf != CPM_OK) return rc_cdf;
+    }
     if (kernel == CPM_KERNEL_ZONE_LDS) {
         return cpm::exact_run(c->zx, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp, static_cast<int>(c->T), c->n, c->cars,
                               c->d_zone0, seed, travel, c->d_dm, d_counts, c->cu_count, [&](int what) { prof_begin(c, what); }, [&](int what) { prof_end(c, what); },
@@ -397,6 +439,10 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
 // the IVP on a layout that cannot overflow: exact buckets when the row fits LDS, one thread per car otherwise
 int32_t ivp_exact(cpm_ctx *c, uint64_t seed)
 {
+    {
+        int32_t rc_cdf = ensure_full_cdf(c);
+        if (rc_cdf != CPM_OK) return rc_cdf;
+    }
     if (pick_kernel(c) != CPM_KERNEL_CAR && cpm::exact_path_fits(static_cast<int>(c->Z))) {
         return cpm::exact_run(c->zx, c->stream, c->d_pdrive, c->d_cdf, static_cast<int>(c->Z), c->Zp, static_cast<int>(c->T), c->n, c->cars,
                               c->d_zone0, seed, false, nullptr, c->d_counts, c->cu_count, [](int) {}, [](int) {}, g_last_error, true, c->d_zone0);
@@ -548,7 +594,9 @@ int32_t cpm_destroy(cpm_ctx *c)
     if (c->have_stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_pdrive);
     dfree(c->d_cdf);
-    dfree(c->d_pdest_work);
+    dfree(c->d_p);
+    dfree(c->d_nf);
+    dfree(c->d_ckpt);
     dfree(c->d_hi);
     dfree(c->d_last);
     dfree(c->d_thr);
@@ -666,17 +714,11 @@ int32_t cpm_set_p_dest(cpm_ctx *c, const double *p_dest)
     }
     if (!p_dest) return fail(CPM_ERR_ARG, "null p_dest");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
-    double *d_p = nullptr;
-    HIP_TRY(hipMalloc(&d_p, bytes));
-    hipError_t e = hipMemcpyAsync(d_p, p_dest, bytes, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) {
-        dfree(d_p);
-        return fail(CPM_ERR_HIP, "upload p_dest: %s", hipGetErrorString(e));
-    }
-    int32_t rc = build_cdf_from_device(c, d_p);
-    (void)hipStreamSynchronize(c->stream);
-    dfree(d_p);
-    return rc;
+    if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
+    c->have_cdf = false;
+    c->have_nf = false;
+    HIP_TRY(hipMemcpyAsync(c->d_p, p_dest, bytes, hipMemcpyHostToDevice, c->stream));
+    return build_rows(c, false);  // (synchronises: the validation flag is read back)
 }
 
 int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *dist)
@@ -924,22 +966,28 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
     }
     if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
-    // The p_destin the CDF is summed from, in the reference's layout.  Kept by the context: a sweep calls this entry once per e_dest
-    // value, and allocating and freeing Z x Z x T x 8 B around every call was measured at up to 0.4 s on a box (the kernels: 3 ms).
-    if (!c->d_pdest_work) HIP_TRY(hipMalloc(&c->d_pdest_work, bytes));
-    double *d_p = c->d_pdest_work;
-    dim3 g1(nblk(c->Z, 64), static_cast<unsigned>(c->Z));
-    hipLaunchKernelGGL(cpm::k_pdest_weights, g1, dim3(64), 0, c->stream, c->d_dm, d_p, static_cast<int>(c->Z),
-                       static_cast<int>(c->T), e_dest, e_is_integer);
-    dim3 g2(nblk(c->Z, 64), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL(cpm::k_pdest_normalise, g2, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z));
+    // createpdestin's weights in the reference's layout + their row sums; the division (:38-46) happens where an entry is read.
+    // Both stay with the context (a sweep calls this entry once per e_dest value: no allocation on that path).
+    if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
+    if (!c->d_nf) HIP_TRY(hipMalloc(&c->d_nf, sizeof(double) * c->Z * c->T));
+    c->have_cdf = false;
+    dim3 g1(nblk(c->Z, 256), static_cast<unsigned>(c->Z));
+    if (c->T == 24)
+        hipLaunchKernelGGL(cpm::k_pdest_weights<24>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
+    else
+        hipLaunchKernelGGL(cpm::k_pdest_weights<0>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
+    hipLaunchKernelGGL(cpm::k_pdest_rowsum, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_p, c->d_nf, static_cast<int>(c->Z));
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_p, bytes, hipMemcpyDeviceToHost, c->stream);
-    int32_t rc = CPM_OK;
-    if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));
-    if (rc == CPM_OK) rc = build_cdf_from_device(c, d_p);
-    if (out) (void)hipStreamSynchronize(c->stream);  // (the host copy of the table)
-    return rc;
+    c->have_nf = true;
+    if (e == hipSuccess && out) {  // createpdestin's array for the host: normalised in place, the row sums are spent
+        hipLaunchKernelGGL(cpm::k_pdest_divide, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream,
+                           c->d_p, c->d_nf, static_cast<int>(c->Z));
+        e = hipGetLastError();
+        c->have_nf = false;
+        if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_p, bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));
+    return build_rows(c, false);  // (synchronises)
 }
 
 int32_t cpm_get_p_drive(cpm_ctx *c, double *out)
@@ -958,6 +1006,10 @@ int32_t cpm_get_cdf_row(cpm_ctx *c, int64_t origin1, int64_t hour1, double *out)
     if (!out) return fail(CPM_ERR_ARG, "null out");
     if (!c->have_cdf) return fail(CPM_ERR_STATE, "p_dest not set");
     if (origin1 < 1 || origin1 > c->Z || hour1 < 1 || hour1 > c->T) return fail(CPM_ERR_ARG, "row index out of range");
+    {
+        int32_t rc_cdf = ensure_full_cdf(c);
+        if (rc_cdf != CPM_OK) return rc_cdf;
+    }
     const double *src = c->d_cdf + (static_cast<size_t>(hour1 - 1) * c->Z + (origin1 - 1)) * c->Zp;
     HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * c->Z, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -984,17 +1036,48 @@ int32_t cpm_synth_tables_skewed(cpm_ctx *c, uint64_t table_seed, int64_t skew_q)
         if (rc_thr != CPM_OK) return rc_thr;
     }
     c->have_pdrive = true;
-    double *d_p = nullptr;
-    HIP_TRY(hipMalloc(&d_p, sizeof(double) * c->Z * c->Z * c->T));
+    if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, sizeof(double) * c->Z * c->Z * c->T));
+    c->have_cdf = false;
+    c->have_nf = false;
     dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, d_p, static_cast<int>(c->Z), table_seed, skew_q);
-    int32_t rc = CPM_OK;
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) rc = fail(CPM_ERR_HIP, "synth_tables: %s", hipGetErrorString(e));
-    if (rc == CPM_OK) rc = build_cdf_from_device(c, d_p);
-    (void)hipStreamSynchronize(c->stream);
-    dfree(d_p);
-    return rc;
+    hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, c->d_p, static_cast<int>(c->Z), table_seed, skew_q);
+    HIP_TRY(hipGetLastError());
+    return build_rows(c, false);
+}
+
+int32_t cpm_synth_datamatrix(cpm_ctx *c, uint64_t table_seed, double density)
+{
+    CTX_TRY(c);
+    {
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
+    if (!(density >= 0.0 && density <= 1.0)) return fail(CPM_ERR_ARG, "synth_datamatrix: density %g", density);
+    const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
+    if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, sizeof(double) * cells * 2));
+    if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * c->Z * c->Z));
+    c->have_dmat = c->have_dist = false;
+    c->tt_valid = false;
+    c->pdrive_mean_valid = false;
+    hipLaunchKernelGGL(cpm::k_synth_datamatrix, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream,
+                       c->d_dm, static_cast<int>(c->Z), static_cast<int>(c->T), table_seed, density);
+    hipLaunchKernelGGL(cpm::k_synth_dist, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z)), dim3(256), 0, c->stream, c->d_dist, static_cast<int>(c->Z),
+                       table_seed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_dmat = c->have_dist = true;
+    return CPM_OK;
+}
+
+int32_t cpm_refresh_tables(cpm_ctx *c, int32_t with_f64_cdf)
+{
+    CTX_TRY(c);
+    {
+        int32_t rc_ivp = finish_ivp(c);
+        if (rc_ivp != CPM_OK) return rc_ivp;
+    }
+    if (!c->have_cdf || !c->d_p) return fail(CPM_ERR_STATE, "refresh_tables: p_dest not set");
+    return build_rows(c, with_f64_cdf != 0);
 }
 
 // ------------------------------------------------------------------ cars
@@ -1225,8 +1308,10 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
         const size_t lds = sizeof(uint32_t) * words;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_pack_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        const size_t th = static_cast<size_t>(hour1 - 1);
         hipLaunchKernelGGL(cpm::k_pack_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
-                           c->d_cdf + row * c->Zp, static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
+                           c->d_ckpt + th * cpm::ckpt_count(static_cast<int>(c->Z)) * c->Z, c->d_p + th * c->Z * c->Z,
+                           c->have_nf ? c->d_nf + th * c->Z : nullptr, static_cast<int>(origin1 - 1), static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
         e = hipGetLastError();
     }
     int h_n = 0;

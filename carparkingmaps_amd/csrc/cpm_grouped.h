@@ -10,8 +10,8 @@
 //     table (cut-point method).  With hi[j] = floor(cdf[j] * 2^32) (0xFFFFFFFF when cdf[j] >= 1) and khi = the high Philox word
 //     = floor(u * 2^32):   hi[j] > khi => cdf[j] >= u   and   hi[j-1] < khi => cdf[j-1] < u,   so the first j with hi[j] >= khi IS
 //     the reference's answer (first j with u <= cdf[j], :38-45) whenever hi[j] > khi strictly.  On a tie (probability ~ Z * 2^-32
-//     per draw), or when u lies above the row total, the car repeats the search on the f64 row in HBM (clamp_u + lower_bound_row,
-//     the code of the other kernels).  Bit-identical to the f64 search by construction; cpm_debug_categorical and
+//     per draw), or when u lies above the row total, the car repeats the reference's f64 walk on the table itself, from the nearest
+//     checkpoint of the running sum (search_exact_ckpt).  Bit-identical to the f64 search by construction; cpm_debug_categorical and
 //     tests/test_gpu_parity.py::test_high_word_search_* drive the tie, saturation and out-of-range branches.
 //     guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G (u16, clamped to Z - 1; G = ceil(log2 Z) - 2).
 //     A row pack = [2^G + 8 u16 guide][Zq u32 hi], Zq = Z + at least 31 entries of 0xFFFFFFFF, rounded to 32.
@@ -73,57 +73,12 @@ inline bool pack_row_fits(int Z)
     return sizeof(uint32_t) * static_cast<size_t>(pack_row_words(pack_zq(Z), pack_guide_bits(Z))) <= 150 * 1024;
 }
 
-// hi part of every row pack and last[t][o], from the canonical CDF (one thread per element, coalesced both ways)
-__global__ __launch_bounds__(256) void k_build_hi32(const double *__restrict__ cdf, uint32_t *__restrict__ rp, double *__restrict__ last,
-                                                    int Z, int Zp, int Zq, int G, int64_t rows)
-{
-    const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
-    if (row >= rows) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Zq) return;
-    uint32_t h = kHiMax;
-    if (j < Z) {
-        const double c = cdf[row * Zp + j];
-        if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated by k_build_cdf)
-        if (j == Z - 1) last[row] = c;
-    }
-    rp[row * pack_row_words(Zq, G) + pack_guide_words(G) + j] = h;
-}
-
 // thr[t][z] = bernoulli_threshold(p_drive[t][z]): the integer the sampler compares the 53-bit draw with (src/resampling.jl:15 as
 // k <= floor(p * 2^53); one scalar load per workgroup instead of f64 arithmetic in every thread)
 __global__ __launch_bounds__(256) void k_build_thr(const double *__restrict__ pdrive, long long *__restrict__ thr, int64_t n)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i < n) thr[i] = bernoulli_threshold(pdrive[i]);
-}
-
-// guide part: guide[m] = min(first j in [0, Z) with hi[j] >= m << (32 - G), Z - 1), m = 0 .. 2^G (entry 2^G and the pad: Z - 1)
-__global__ __launch_bounds__(256) void k_build_guide(uint32_t *__restrict__ rp, int Z, int Zq, int G, int64_t rows)
-{
-    const int64_t row = blockIdx.y + static_cast<int64_t>(blockIdx.z) * gridDim.y;
-    if (row >= rows) return;
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= (1 << G) + 8) return;
-    uint32_t *pack = rp + row * pack_row_words(Zq, G);
-    const uint32_t *hi = pack + pack_guide_words(G);
-    int lo = Z - 1;
-    if (m < (1 << G)) {
-        const uint32_t edge = static_cast<uint32_t>(m) << (32 - G);
-        int n = Z;
-        lo = 0;
-        while (n > 0) {
-            const int half = n >> 1;
-            if (hi[lo + half] < edge) {
-                lo += half + 1;
-                n -= half + 1;
-            } else {
-                n = half;
-            }
-        }
-        lo = min(lo, Z - 1);
-    }
-    reinterpret_cast<uint16_t *>(pack)[m] = static_cast<uint16_t>(lo);
 }
 
 // ------------------------------------------------------------------------------------------------ bucketing
@@ -210,7 +165,9 @@ struct GroupedArgs {
     const uint32_t *rp_t;     // [Z][RW] row packs of this hour
     const double *last_t;     // [Z] row totals (f64)
     const long long *thr_t;   // [Z] Bernoulli thresholds floor(p_drive * 2^53) of this hour
-    const double *cdf_t;      // [Z][Zp] canonical CDF rows of this hour (exact fallback)
+    const double *ckpt_t;     // [nck][Z] every 32nd value of this hour's running sums (exact fallback: search_exact_ckpt)
+    const double *p_t;        // [Z dest][Z origin] this hour's slab of p_destin as the reference lays it out
+    const double *nf_t;       // [Z] its row normalisers, or null when the table is normalised already
     uint32_t *ids_next;       // [Z*cap]  next hour's buckets: the stayers (grouped) / dest | drive << 31 per slot (plain)
     uint32_t *cnt_next;       // [Z] stayers (grouped; k_grouped_place adds the arrivals)
     uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
@@ -247,6 +204,170 @@ __device__ __forceinline__ void put32(uint32_t *p, uint32_t i, uint32_t v)
 // lane 0's value to the whole wave (every lane active): one v_readfirstlane instead of the LDS crossbar of __shfl
 __device__ __forceinline__ uint32_t from_lane0(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 
+// ------------------------------------------------------------------------------------------------ row tables in ONE pass
+// Everything the samplers read of p_destin is derived here from the table as the reference lays it out, p[o + Z*(d + Z*t)]
+// (origin fastest; `nf` != null: the table holds createpdestin's unnormalised weights and an entry is p / nf[t][o] where nf > 0,
+// src/createpdestin.jl:38-46), in one pass over it:
+//   * the running sum of a row, left to right in f64 -- range_up = range_up + distribution[j] of src/resampling.jl:39; a tree scan
+//     would move boundaries by ulps -- by ONE lane per origin (the 64 origins of a tile are 64 consecutive words of p: coalesced);
+//   * CDF && cdf  : the canonical CDF rows cdf[t][o][d] (f64, padded with +inf to Zp) -- only for the kernels that search f64 rows
+//                   (one thread per car, exact layout); the grouped path never asks for them;
+//   * PACK        : the row packs of the grouped sampler: hi[j] = floor(cdf[j] * 2^32) (0xFFFFFFFF from 1.0 on and in the pad) and the
+//                   guide, guide[m] = min(first j with hi[j] >= m << (32 - G), Z - 1), which falls out of the same walk: destination j
+//                   owns the entries m with hi[j-1] < m << sh <= hi[j], i.e. (hi[j-1] >> sh) + 1 .. hi[j] >> sh, and Z - 1 owns the rest;
+//   * last[t][o]  : the row total;
+//   * ckpt[t][k][o] = cdf[min(32 k + 31, Z - 1)]: every 32nd value of the running sum.  A tie of the high-word search repeats the
+//                   reference's walk from the checkpoint in front of it (search_exact_ckpt): at most 32 sequential additions of the
+//                   same p entries, bit-identical to the full running sum, without 8 bytes per destination in HBM.
+// Block = 5 waves: wave 0 sums (64 loads in flight per lane), waves 1-4 take the 64 x 64 tile it leaves in LDS (two buffers, one
+// barrier per tile) and write it out row-major: consecutive lanes, consecutive destinations of one row.
+// (Round 2 built the same in three launches -- CDF, high words from the CDF just written, guide by a binary search per entry over the
+// high words just written -- 13.4 GB of traffic for the 8.3 GB one pass needs, 3.77 ms at S4k.)
+constexpr int kRowTile = 64;
+constexpr int kRowBlock = 320;
+constexpr int kCkptStride = 32;
+__host__ __device__ inline int ckpt_count(int Z) { return (Z + kCkptStride - 1) / kCkptStride; }
+constexpr size_t kRowLds = sizeof(double) * 2 * kRowTile * (kRowTile + 1) + sizeof(uint32_t) * kRowTile;
+
+template <bool CDF, bool PACK>
+__global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__restrict__ p, const double *__restrict__ nf, double *__restrict__ cdf,
+                                                          uint32_t *__restrict__ rp, double *__restrict__ last, double *__restrict__ ckpt,
+                                                          int Z, int Zp, int Zq, int G, int *err)
+{
+    extern __shared__ __attribute__((aligned(16))) double row_lds[];
+    double(*tile)[kRowTile][kRowTile + 1] = reinterpret_cast<double(*)[kRowTile][kRowTile + 1]>(row_lds);  // [2][64 origins][64 destinations]
+    uint32_t *prevh = reinterpret_cast<uint32_t *>(row_lds + 2 * kRowTile * (kRowTile + 1));              // last high word of each row's previous tile
+    const int t = blockIdx.y;
+    const int o0 = blockIdx.x * kRowTile;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dmax = PACK ? Zq : Zp;  // (Zq >= Zp)
+    const int nt = (dmax + kRowTile - 1) / kRowTile;
+    if (wave == 0) {
+        // ---- the running sums: lane = origin
+        const int o = o0 + lane;
+        const bool live = o < Z;
+        const double *src = p + static_cast<size_t>(t) * Z * Z + o0;  // (wave-uniform: a load is scalar row base + the lane's 8-byte offset)
+        const int lane_c = live ? lane : 0;
+        double nfv = 0.0;
+        if (nf != nullptr && live) nfv = nf[static_cast<size_t>(t) * Z + o];
+        const bool div = nfv > 0;  // (NaN: false -- the row stays as it is, src/createpdestin.jl:40)
+        const int nck = ckpt_count(Z);
+        double *ck = ckpt ? ckpt + static_cast<size_t>(t) * nck * Z + o : nullptr;
+        double run = 0.0;
+        bool bad = false;
+        constexpr int H = kRowTile / 2;
+        double xa[H], xb[H];
+        auto load_half = [&](double(&x)[H], int dbase) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const int d = dbase + u;
+                x[u] = (d < Z) ? (src + static_cast<size_t>(d) * Z)[lane_c] : 0.0;
+            }
+        };
+        auto consume_half = [&](double(&x)[H], int dbase, int buf, int jbase) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const int d = dbase + u;
+                double v = __builtin_huge_val();
+                if (d < Z) {
+                    const double y = div ? x[u] / nfv : x[u];
+                    bad |= !(y >= 0.0);
+                    run = run + y;
+                    v = run;
+                    if (live && (u == H - 1 || d == Z - 1)) {  // (32 | dbase: u == 31 is every 32nd destination)
+                        if (ck) ck[static_cast<size_t>(d / kCkptStride) * Z] = run;
+                        if (d == Z - 1 && last) last[static_cast<size_t>(t) * Z + o] = run;
+                    }
+                }
+                tile[buf][lane][jbase + u] = v;
+            }
+        };
+        load_half(xa, 0);
+        for (int k = 0; k < nt; ++k) {
+            const int d0 = k * kRowTile;
+            load_half(xb, d0 + H);
+            consume_half(xa, d0, k & 1, 0);
+            if (k + 1 < nt) load_half(xa, d0 + kRowTile);
+            consume_half(xb, d0 + H, k & 1, H);
+            lds_barrier();  // (LDS only: the loads of the next tile stay in flight)
+        }
+        if (bad && live) atomicOr(err, 1);
+        return;
+    }
+    // ---- the tiles out: lane = destination
+    const int nrow = min(kRowTile, Z - o0);
+    const int sh = 32 - G;
+    const int gw = pack_guide_words(G);
+    const size_t rw = static_cast<size_t>(pack_row_words(Zq, G));
+    for (int k = 0; k < nt; ++k) {
+        lds_barrier();
+        const int d = k * kRowTile + lane;
+        for (int r = wave - 1; r < nrow; r += kRowBlock / 64 - 1) {
+            const double c = tile[k & 1][r][lane];
+            const size_t row = static_cast<size_t>(t) * Z + o0 + r;
+            if (CDF && d < Zp) cdf[row * Zp + d] = c;
+            if (PACK) {
+                uint32_t *pack = rp + row * rw;
+                uint32_t h = kHiMax;
+                if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated), +inf in the pad
+                if (d < Zq) pack[gw + d] = h;
+                uint32_t hp = __shfl_up(h, 1, 64);
+                if (lane == 0) hp = prevh[r];
+                if (lane == 63) prevh[r] = h;  // (row r is this wave's in every tile)
+                int m0 = (d == 0) ? 0 : static_cast<int>(hp >> sh) + 1;
+                int m1 = (d < Z) ? static_cast<int>(h >> sh) : -1;
+                if (d == Z - 1) m1 = (1 << G) + 7;  // the entries no destination reaches, and the pad: Z - 1
+                int n = m1 - m0 + 1;
+                uint16_t *guide = reinterpret_cast<uint16_t *>(pack);
+                const uint16_t dv = static_cast<uint16_t>(d);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < n) guide[m0 + i] = dv;
+                unsigned long long more = ballot64(n > 4);  // long ranges (peaky rows, empty rows): the whole wave fills them
+                while (more) {
+                    const int srcl = __builtin_ctzll(more);
+                    more &= more - 1;
+                    const int s0 = __shfl(m0, srcl, 64) + 4, cnt = __shfl(n, srcl, 64) - 4;
+                    const uint16_t v = static_cast<uint16_t>(k * kRowTile + srcl);
+                    for (int i = lane; i < cnt; i += 64) guide[s0 + i] = v;
+                }
+            }
+        }
+    }
+}
+
+// The categorical draw of src/resampling.jl:38-45 for ONE car on the table itself (ties of the high-word search, draws above the row
+// total): first j with cdf[j] >= ue -- found from the checkpoints (binary search over every 32nd value of the running sum), then the
+// reference's own walk, run = run + p[j], from the checkpoint in front.  Same additions in the same order as the full running sum.
+__device__ __noinline__ uint32_t search_exact_ckpt(const double *__restrict__ ckpt_t, const double *__restrict__ p_t, const double *__restrict__ nf_t,
+                                                   int Z, int o, double uc, double last)
+{
+    const double ue = clamp_u(uc, last);
+    int lo = 0, n = ckpt_count(Z);
+    while (n > 0) {  // first k with ckpt[k] >= ue (the last one is the row total >= ue)
+        const int half = n >> 1;
+        if (ckpt_t[static_cast<size_t>(lo + half) * Z + o] < ue) {
+            lo += half + 1;
+            n -= half + 1;
+        } else {
+            n = half;
+        }
+    }
+    lo = min(lo, ckpt_count(Z) - 1);
+    double run = lo ? ckpt_t[static_cast<size_t>(lo - 1) * Z + o] : 0.0;
+    const double nfv = nf_t ? nf_t[o] : 0.0;
+    const bool div = nfv > 0;
+    int j = lo * kCkptStride;
+    const int jend = min(j + kCkptStride, Z);
+    for (; j < jend; ++j) {
+        const double x = p_t[static_cast<size_t>(j) * Z + o];
+        run = run + (div ? x / nfv : x);
+        if (run >= ue) break;
+    }
+    return static_cast<uint32_t>(min(j, Z - 1));
+}
+
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 
@@ -279,12 +400,6 @@ __device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
         asm volatile("s_waitcnt vmcnt(%3)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]) : "n"(NQ) : "memory");
     else
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(id[0]), "+v"(id[1]) : "n"(NQ) : "memory");
-}
-
-// The f64 search of the other kernels, on the row where it lies in HBM (rare: ties and u above the row total).
-__device__ __noinline__ uint32_t search_exact_row(const double *__restrict__ cdf_row, int Z, double uc, double last)
-{
-    return static_cast<uint32_t>(lower_bound_row(cdf_row, Z, clamp_u(uc, last)));
 }
 
 // CPT draws against the staged pack, in lockstep (CPT independent LDS reads in flight per step):
@@ -527,7 +642,6 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
     const uint32_t hi_last = hi[Z - 1];
-    const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t nd = 0;
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
@@ -543,7 +657,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
+                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo[c], khi[c]), last);
         }
     }
     CPM_SSTAMP(4);
@@ -598,7 +712,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         want1[0] = drive1 & (last != 0.0);
         pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
         if (!want1[0]) dest1[0] = z;
-        else if (!ok1[0]) dest1[0] = search_exact_row(cdf_row, Z, u53(clo1[0], khi1[0]), last);
+        else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo1[0], khi1[0]), last);
         if (GROUPED) {
             const unsigned long long m1 = ballot64(valid1 & !drive1);
             uint32_t b1 = 0;
@@ -679,7 +793,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
     const uint32_t hi_last = hi[Z - 1];
-    const double *cdf_row = a.cdf_t + static_cast<size_t>(z) * a.Zp;
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
@@ -710,7 +823,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         if (__builtin_expect(any64(anyx), 0)) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_row(cdf_row, Z, u53(clo[c], khi[c]), last);
+                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo[c], khi[c]), last);
         }
         // stayers: one global ticket per wave
         unsigned long long mS[CPT];
@@ -1238,7 +1351,8 @@ inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
 // installed row, through the same staging, search and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
 __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__restrict__ pack_g, const double *__restrict__ last_p,
-                                                           const double *__restrict__ cdf_row, int Z, int Zq, int G, int64_t n,
+                                                           const double *__restrict__ ckpt_t, const double *__restrict__ p_t,
+                                                           const double *__restrict__ nf_t, int origin, int Z, int Zq, int G, int64_t n,
                                                            const uint64_t *__restrict__ k53, int64_t *__restrict__ out, int *__restrict__ n_exact)
 {
     extern __shared__ uint32_t pack[];
@@ -1274,7 +1388,7 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
             continue;
         }
         if (!ok[0]) {
-            dest[0] = search_exact_row(cdf_row, Z, static_cast<double>(k) * 0x1.0p-53, last);
+            dest[0] = search_exact_ckpt(ckpt_t, p_t, nf_t, Z, origin, static_cast<double>(k) * 0x1.0p-53, last);
             atomicAdd(n_exact, 1);
         }
         out[i] = static_cast<int64_t>(dest[0]) + 1;
@@ -1410,7 +1524,9 @@ struct GroupedTables {
     const uint32_t *rp;      // [T][Z][RW]
     const double *last;      // [T][Z]
     const long long *thr;    // [T][Z]
-    const double *cdf;       // [T][Z][Zp]
+    const double *ckpt;      // [T][nck][Z] checkpoints of the running sums
+    const double *p;         // [T][Z dest][Z origin] p_destin (reference layout)
+    const double *nf;        // [T][Z] row normalisers or null
     const double2 *tt;       // [T][Z][Z] travel table (k_build_travel_table) or nullptr
     int Z, Zp, Zq, T;
 };
@@ -1492,7 +1608,9 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.rp_t = tb.rp + static_cast<size_t>(t) * Z * rw;
         a.last_t = tb.last + static_cast<size_t>(t) * Z;
         a.thr_t = tb.thr + static_cast<size_t>(t) * Z;
-        a.cdf_t = tb.cdf + static_cast<size_t>(t) * Z * tb.Zp;
+        a.ckpt_t = tb.ckpt + static_cast<size_t>(t) * ckpt_count(Z) * Z;
+        a.p_t = tb.p + static_cast<size_t>(t) * Z * Z;
+        a.nf_t = tb.nf ? tb.nf + static_cast<size_t>(t) * Z : nullptr;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
         a.D = w.Dq + (history ? w.run_words() * t : 0);

@@ -4,7 +4,8 @@
 //   pdrive [T][Z]        f64   == Julia's column-major Z x T, zone contiguous
 //   cdf    [T][Z][Zp]    f64   canonical CDF rows, destination contiguous, row padded to
 //                              Zp = roundup(Z,16) with +inf (a row is a whole number of
-//                              128-B lines and starts on one)
+//                              128-B lines and starts on one); built on first need (k_build_rows,
+//                              cpm_grouped.h): only the car and exact-layout kernels search f64 rows
 //   zone0  [C]           u32   current (initial) zone of each local car, 0-based
 //   rec    [T][C]        u32   per resampling hour: destination zone | drive flag << 31
 //   counts [2][T][Z]     i64   parking | driving zone x hour histogram (+1 word: q16 time sum)
@@ -84,65 +85,6 @@ __global__ void k_zones_to_i64(int64_t *zones1, const uint32_t *zone0, int64_t n
 }
 
 // ---------------------------------------------------------------------------------------
-// Canonical CDF build.  Input: p_dest in the reference's layout p[o + Z*(d + Z*t)]
-// (origin fastest).  One lane per origin walks d left to right with a plain f64 running
-// sum -- exactly range_up = range_up + distribution[j] of src/resampling.jl:39; a tree scan
-// would move boundaries by ULPs and break bit-exactness.  Loads are coalesced across the
-// 64 origins of a wave; the 64x64 tile goes through LDS so the row-major stores are
-// coalesced too.  Also validates the table (NaN / negative entries -> *err).
-// ---------------------------------------------------------------------------------------
-constexpr int kCdfTile = 64;
-constexpr int kCdfBatch = 32;
-
-__global__ __launch_bounds__(kCdfTile) void k_build_cdf(const double *__restrict__ p, double *__restrict__ cdf,
-                                                        int Z, int Zp, int *err)
-{
-    __shared__ double tile[kCdfTile][kCdfTile + 1];
-    const int t = blockIdx.y;
-    const int o0 = blockIdx.x * kCdfTile;
-    const int lane = threadIdx.x;
-    const int o = o0 + lane;
-    const double *src = p + static_cast<size_t>(t) * Z * Z + o;
-    double *dst = cdf + (static_cast<size_t>(t) * Z + o0) * Zp;
-    double run = 0.0;
-    bool bad = false;
-    for (int d0 = 0; d0 < Zp; d0 += kCdfTile) {
-        if (o < Z) {
-            // the running sum is sequential (src/resampling.jl:39), the loads are not: kCdfBatch of them in flight per lane
-#pragma unroll
-            for (int j0 = 0; j0 < kCdfTile; j0 += kCdfBatch) {
-                double x[kCdfBatch];
-#pragma unroll
-                for (int u = 0; u < kCdfBatch; ++u) {
-                    const int d = d0 + j0 + u;
-                    x[u] = (d < Z) ? src[static_cast<size_t>(d) * Z] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < kCdfBatch; ++u) {
-                    const int d = d0 + j0 + u;
-                    double v;
-                    if (d < Z) {
-                        bad |= !(x[u] >= 0.0);
-                        run = run + x[u];
-                        v = run;
-                    } else {
-                        v = __builtin_huge_val();
-                    }
-                    tile[lane][j0 + u] = v;
-                }
-            }
-        }
-        __syncthreads();
-        int nrow = min(kCdfTile, Z - o0);
-        int d = d0 + lane;
-        if (d < Zp)
-            for (int r = 0; r < nrow; ++r) dst[static_cast<size_t>(r) * Zp + d] = tile[r][lane];
-        __syncthreads();
-    }
-    if (bad) atomicOr(err, 1);
-}
-
-// ---------------------------------------------------------------------------------------
 // Synthetic tables of SURVEY.md 8(d) (bench / parity inputs), bit-identical to
 // orc_synth_p_drive / orc_synth_p_dest_dense of the oracle.
 // ---------------------------------------------------------------------------------------
@@ -184,6 +126,43 @@ __global__ void k_synth_p_dest(double *__restrict__ p, int Z, uint64_t table_see
         if (nf > 0) w = w / nf;
         dst[static_cast<size_t>(d) * Z] = w;
     }
+}
+
+// Melbourne-shaped synthetic datamatrix + distance matrix (8.68 % of the (o, d, t) cells hold a mean of 300-2400 s
+// and a standard deviation of 10-40 % of it; distances from random centroids), generated where it is used -- bench.py's per-dataset
+// figures start from it without 2 GB crossing PCIe.  Bit-identical to orc_synth_datamatrix of the oracle (table streams 0x102-0x104).
+constexpr uint32_t kStreamDataA = 0x102u, kStreamDataB = 0x103u, kStreamCentroid = 0x104u;
+__global__ __launch_bounds__(256) void k_synth_datamatrix(double *__restrict__ dm, int Z, int T, uint64_t table_seed, double density)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y, t = blockIdx.z;
+    if (o >= Z) return;
+    double ua, ub, uc, ud;
+    car_uniforms(table_seed, (static_cast<uint64_t>(static_cast<uint32_t>(d)) << 32) | static_cast<uint32_t>(o), static_cast<uint32_t>(t), kStreamDataA, ua, ub);
+    car_uniforms(table_seed, (static_cast<uint64_t>(static_cast<uint32_t>(d)) << 32) | static_cast<uint32_t>(o), static_cast<uint32_t>(t), kStreamDataB, uc, ud);
+    double mean = 0, sd = 0;
+    if (o != d && ua < density) {
+        mean = 300.0 + 2100.0 * ub;
+        sd = mean * (0.1 + 0.3 * uc);
+    }
+    const size_t cell = static_cast<size_t>(o) + static_cast<size_t>(Z) * (d + static_cast<size_t>(Z) * t);
+    dm[cell] = mean;
+    dm[cell + static_cast<size_t>(Z) * Z * T] = sd;
+}
+
+__global__ __launch_bounds__(256) void k_synth_dist(double *__restrict__ dist, int Z, uint64_t table_seed)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= Z) return;
+    double ui, vi, uj, vj;
+    car_uniforms(table_seed, static_cast<uint64_t>(static_cast<uint32_t>(i)), 0u, kStreamCentroid, ui, vi);
+    car_uniforms(table_seed, static_cast<uint64_t>(static_cast<uint32_t>(j)), 0u, kStreamCentroid, uj, vj);
+    const double lat_i = -38.5 + 1.5 * ui, lon_i = 144.0 + 2.0 * vi, lat_j = -38.5 + 1.5 * uj, lon_j = 144.0 + 2.0 * vj;
+    const double dlon = 0.79 * (lon_i - lon_j), dlat = lat_i - lat_j;  // equirectangular, cos(lat) frozen at 0.79 (src/processgeodata.jl:157)
+    double v = (i == j) ? 1.0 : 111.3 * sqrt(dlon * dlon + dlat * dlat);
+    if (v == 0) v = 1.0;
+    dist[i + static_cast<size_t>(Z) * j] = v;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -108,58 +108,88 @@ __global__ void k_pdrive_final(const double *__restrict__ mean_sum, double *__re
     if (thr) thr[i + static_cast<size_t>(t) * Z] = bernoulli_threshold(v);
 }
 
-// unnormalised p_dest[i,j,t] = ((m - min_t m) / (max_t m - min_t m))^e_dest   (createpdestin.jl:10-28)
-__global__ void k_pdest_weights(const double *__restrict__ dm, double *__restrict__ p, int Z, int T, double e_dest,
-                                int e_is_integer)
+// unnormalised p_dest[i,j,t] = ((m - min_t m) / (max_t m - min_t m))^e_dest   (createpdestin.jl:10-28).  One thread per (origin,
+// destination) pair, the origin on the lane.  TT > 0: the TT hourly means of the pair are loaded once, all in flight together, and
+// stay in registers for the extrema and the weights (T = 24: main.jl:42); TT == 0: any T, the day is read twice.
+template <int TT>
+__global__ __launch_bounds__(256) void k_pdest_weights(const double *__restrict__ dm, double *__restrict__ p, int Z, int T, double e_dest,
+                                                       int e_is_integer)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
     if (i >= Z) return;
-    size_t base = i + static_cast<size_t>(j) * Z;
-    size_t slab = static_cast<size_t>(Z) * Z;
-    double mx = dm[base], mn = dm[base];
-    for (int t = 1; t < T; ++t) {
-        double v = dm[base + t * slab];
-        mx = jl_max(mx, v);
-        mn = jl_min(mn, v);
-    }
-    for (int t = 0; t < T; ++t) {
-        double w = 0.0;
-        if (mx > 0) {
-            double x = (dm[base + t * slab] - mn) / (mx - mn);
-            w = e_is_integer ? pow_int(x, static_cast<long>(e_dest)) : pow_f64(x, e_dest);
+    const size_t base = i + static_cast<size_t>(j) * Z;
+    const size_t slab = static_cast<size_t>(Z) * Z;
+    if constexpr (TT > 0) {
+        double v[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) v[t] = dm[base + t * slab];
+        double mx = v[0], mn = v[0];
+#pragma unroll
+        for (int t = 1; t < TT; ++t) {
+            mx = jl_max(mx, v[t]);
+            mn = jl_min(mn, v[t]);
         }
-        p[base + t * slab] = w;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            double w = 0.0;
+            if (mx > 0) {
+                const double x = (v[t] - mn) / (mx - mn);
+                w = e_is_integer ? pow_int(x, static_cast<long>(e_dest)) : pow_f64(x, e_dest);
+            }
+            p[base + t * slab] = w;
+        }
+    } else {
+        double mx = dm[base], mn = dm[base];
+        for (int t = 1; t < T; ++t) {
+            const double v = dm[base + t * slab];
+            mx = jl_max(mx, v);
+            mn = jl_min(mn, v);
+        }
+        for (int t = 0; t < T; ++t) {
+            double w = 0.0;
+            if (mx > 0) {
+                const double x = (dm[base + t * slab] - mn) / (mx - mn);
+                w = e_is_integer ? pow_int(x, static_cast<long>(e_dest)) : pow_f64(x, e_dest);
+            }
+            p[base + t * slab] = w;
+        }
     }
 }
 
-// normalise per (i,t): nf = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33); divide if nf > 0 (:38-46)
-__global__ void k_pdest_normalise(double *__restrict__ p, int Z)
+// nf[i,t] = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33).  The division by it
+// (:38-46) is NOT a pass of its own: k_build_rows and search_exact_ckpt divide an entry where they read it (p / nf where nf > 0) --
+// the table stays as createpdestin's weights and is read once for the sums and once for everything the samplers use.
+constexpr int kSumBatch = 32;
+__global__ __launch_bounds__(64) void k_pdest_rowsum(const double *__restrict__ p, double *__restrict__ nf, int Z)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int t = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
     if (i >= Z) return;
-    double *row = p + static_cast<size_t>(t) * Z * Z + i;
-    double nf = 0.0;
+    const double *row = p + static_cast<size_t>(t) * Z * Z + i;
+    double s = 0.0;
     int j = 0;
-    for (; j + kTabBatch <= Z; j += kTabBatch) {  // loads in batches, sum in order (see k_pdrive_mean)
-        double v[kTabBatch];
+    for (; j + kSumBatch <= Z; j += kSumBatch) {  // loads in batches, sum in order (see k_pdrive_mean)
+        double v[kSumBatch];
 #pragma unroll
-        for (int u = 0; u < kTabBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
+        for (int u = 0; u < kSumBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
 #pragma unroll
-        for (int u = 0; u < kTabBatch; ++u) nf = nf + v[u];
+        for (int u = 0; u < kSumBatch; ++u) s = s + v[u];
     }
-    for (; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
-    if (nf > 0) {
-        j = 0;
-        for (; j + kTabBatch <= Z; j += kTabBatch) {
-            double v[kTabBatch];
-#pragma unroll
-            for (int u = 0; u < kTabBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
-#pragma unroll
-            for (int u = 0; u < kTabBatch; ++u) row[static_cast<size_t>(j + u) * Z] = v[u] / nf;
-        }
-        for (; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
+    for (; j < Z; ++j) s = s + row[static_cast<size_t>(j) * Z];
+    nf[i + static_cast<size_t>(t) * Z] = s;
+}
+
+// p[i,j,t] /= nf[i,t] where nf > 0 (createpdestin.jl:38-46) in place: only when the caller wants createpdestin's array on the host
+__global__ __launch_bounds__(256) void k_pdest_divide(double *__restrict__ p, const double *__restrict__ nf, int Z)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, t = blockIdx.z;
+    if (i >= Z) return;
+    const double n = nf[i + static_cast<size_t>(t) * Z];
+    if (n > 0) {
+        double *q = p + i + static_cast<size_t>(Z) * (j + static_cast<size_t>(Z) * t);
+        *q = *q / n;
     }
 }
 

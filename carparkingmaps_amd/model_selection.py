@@ -84,6 +84,7 @@ class Evaluator:
     measured_activity: object = None
     measured_parking: object = None
     travel: bool = True
+    fallbacks: int = 0      # pipelined points whose asynchronous step overflowed a bucket region and were evaluated again, blocking
     _e_dest: object = field(default=None, repr=False)
     _pipe: object = field(default=None, repr=False)
 
@@ -146,7 +147,12 @@ class Evaluator:
         Z, T = self.sampler.Z, self.sampler.T
         zt = Z * T
         if flat[2 * zt + 1] != 0:
-            return self.evaluate(pt)
+            # (evaluate() installs pt's tables again -- the next point's are in place by now -- and the blocking resample grows the
+            #  regions; the point already in flight behind this one was enqueued on the old regions and comes back here too)
+            self.fallbacks += 1
+            out = self.evaluate(pt)
+            out["fallback"] = True
+            return out
         both = flat[:2 * zt].copy()                           # (the pinned twin is reused two points later)
         parking = both[:zt].reshape((T, Z)).T                 # Julia order (Z, T): views, no second copy
         driving = both[zt:].reshape((T, Z)).T
@@ -265,6 +271,7 @@ def grid_sweep(evaluator, grid, rank=0, world_size=1, gather=True, checksums=Fal
 
     for i, r in results():
         local[i] = {k: v for k, v in r.items() if np.isscalar(v)}
+        local[i]["fallback"] = bool(r.get("fallback", False))   # evaluated twice: its asynchronous step had overflowed
         local[i]["driving_total"] = int(r["driving"].sum())
         local[i]["hours_hold_all_cars"] = bool((r["parking"].sum(axis=0) == C).all())
         if checksums:

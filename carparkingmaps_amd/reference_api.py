@@ -65,10 +65,16 @@ def invalidate():
         d.clear()
 
 
+_STAMP_CHUNK = 1 << 20
+
+
 def _stamp(a):
-    """(address, shape, strides, content sum) of a host array.  The content sum is one pass over the WHOLE buffer (a wrapping
-    uint64 sum of its words, ~10 GB/s: far below the PCIe upload + table build it can save), so an array edited in place -- the
-    notebook's tuning loops do that -- never leaves stale tables on the device.  params.trust_unchanged skips the pass."""
+    """(address, shape, strides, content fingerprint) of a host array.  The fingerprint is one pass over the WHOLE buffer, and it
+    depends on WHERE every word sits: a wrapping uint64 sum of the words plus a wrapping sum of word x (2 x position + 1) (an odd
+    weight: no word is ever multiplied away), taken over chunks of 2^20 words.  So an array edited in place -- the notebook's tuning
+    loops do that --, and also one permuted in place (two zones' rows swapped, a sort), never leaves stale tables on the device;
+    a plain sum would not see the latter.  ~5 GB/s: far below the PCIe upload + table build it can save.  params.trust_unchanged
+    skips the pass."""
     a = np.asarray(a)
     head = (a.__array_interface__["data"][0], a.shape, a.strides, str(a.dtype))
     if params.trust_unchanged:
@@ -77,7 +83,17 @@ def _stamp(a):
         words = a.reshape(-1, order="A").view(np.uint64)
     else:
         words = np.ascontiguousarray(a, dtype=np.float64).reshape(-1).view(np.uint64)
-    return head + (int(np.add.reduce(words, dtype=np.uint64)) if words.size else 0,)
+    plain = weighted = 0
+    with np.errstate(over="ignore"):
+        odd = np.arange(1, 2 * _STAMP_CHUNK, 2, dtype=np.uint64)                  # 2 i + 1 inside a chunk
+        for k, lo in enumerate(range(0, words.size, _STAMP_CHUNK)):
+            w = words[lo:lo + _STAMP_CHUNK]
+            ps = int(np.add.reduce(w, dtype=np.uint64))
+            ws = int(np.add.reduce(w * odd[:w.size], dtype=np.uint64))
+            plain = (plain + ps) & 0xFFFFFFFFFFFFFFFF
+            # word i of chunk k has global weight 2 (k L + i) + 1 = (2 i + 1) + 2 k L
+            weighted = (weighted + ws + 2 * k * _STAMP_CHUNK * ps) & 0xFFFFFFFFFFFFFFFF
+    return head + (plain, weighted)
 
 
 def _ensure(key, s, name, array, setter):

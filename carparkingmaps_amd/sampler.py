@@ -145,6 +145,14 @@ class Sampler:
         """Procedural bench tables; skew_q > 0: destination popularity 1 / (skew_q + rank), see include/cpm.h."""
         _lib.check(self._L.cpm_synth_tables_skewed(self._h, int(table_seed), int(skew_q)))
 
+    def synth_datamatrix(self, table_seed, density=0.0868):
+        """Melbourne-shaped synthetic datamatrix + distance matrix, generated on the device."""
+        _lib.check(self._L.cpm_synth_datamatrix(self._h, int(table_seed), float(density)))
+
+    def refresh_tables(self, with_f64_cdf=False):
+        """Re-derive the row tables from the resident p_destin (the one pass the installing calls end in); for measurement."""
+        _lib.check(self._L.cpm_refresh_tables(self._h, 1 if with_f64_cdf else 0))
+
     def get_p_drive(self):
         out = np.zeros((self.Z, self.T), dtype=np.float64, order="F")
         _lib.check(self._L.cpm_get_p_drive(self._h, _vp(out)))

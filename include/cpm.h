@@ -91,7 +91,8 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
  * or run outgrew it) */
 #define CPM_INFO_KERNEL 1
 #define CPM_INFO_CAP_MULT 2
-#define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above twice a workgroup's slots was seen */
+#define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above FOUR times a workgroup's slots was seen
+                            * (kHeavy in cpm_grouped.h; lighter overflow stays with the overflow rounds of the zone's own workgroup) */
 int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own, which is created when a call first needs it.
  * Contexts meant to run side by side (two resamples interleave on the chip) are each given their stream right behind
@@ -195,6 +196,15 @@ int32_t cpm_synth_tables(cpm_ctx *ctx, uint64_t table_seed);
 /* the same with skewed destination popularity (bench.py --skew): weight u^2 / (skew_q + rank(d)), rank(d) = (7919 d + 13) mod Z
  * -- a few destinations many times as likely as the mean, like real Uber Movement rows (README.md output_24_0.svg) */
 int32_t cpm_synth_tables_skewed(cpm_ctx *ctx, uint64_t table_seed, int64_t skew_q);
+/* Melbourne-shaped synthetic datamatrix + distance matrix of SURVEY.md 8(d), generated on device (bench inputs for the per-dataset
+ * flow main.jl:79-95: 8.68 % of the (o, d, t) cells populated, README.md:302-310); enables cpm_build_* and CPM_FLAG_TRAVEL like
+ * cpm_set_datamatrix */
+int32_t cpm_synth_datamatrix(cpm_ctx *ctx, uint64_t table_seed, double density);
+/* re-derives the samplers' row tables (row totals, running-sum checkpoints, row packs; with_f64_cdf != 0: the canonical f64 CDF rows
+ * too) from the p_destin resident in the context: the one pass cpm_set_p_dest / cpm_build_p_dest / cpm_synth_tables end in
+ * (src/resampling.jl:39's running sum).  For measurement (bench.py's table_build record) and after cpm_set_option changes nothing it
+ * reads; results are those of the installing call. */
+int32_t cpm_refresh_tables(cpm_ctx *ctx, int32_t with_f64_cdf);
 /* with CPM_OPT_PROFILE: durations (ms) of the hourly launches of the profiled kernel (CPM_OPT_PROFILE_KERNEL) made by
  * cpm_resample* since the option was last set, in launch order (hipEvents on the context's
  * stream); returns the number written through *n_out */

@@ -21,7 +21,7 @@ mutable struct Ctx
     h::Ptr{Cvoid}
     Z::Int
     T::Int
-    resident::Dict{Symbol,Tuple{UInt,Tuple,UInt64}}   # table name => (address, size, content sum) of the host array last uploaded
+    resident::Dict{Symbol,Tuple{UInt,Tuple,UInt64,UInt64}}   # table name => (address, size, content fingerprint) of the host array last uploaded
 end
 
 const _ctx = Dict{Tuple{Int,Int,Int},Ctx}()
@@ -43,7 +43,7 @@ function context(Z::Integer, T::Integer=_T(), device::Integer=_dev())
     get!(_ctx, (Int(Z), Int(T), Int(device))) do
         h = Ref{Ptr{Cvoid}}(C_NULL)
         _check(ccall((:cpm_create, libcpm), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Cint), h, Z, T, device))
-        Ctx(h[], Int(Z), Int(T), Dict{Symbol,Tuple{UInt,Tuple,UInt64}}())
+        Ctx(h[], Int(Z), Int(T), Dict{Symbol,Tuple{UInt,Tuple,UInt64,UInt64}}())
     end
 end
 
@@ -58,9 +58,19 @@ end
 invalidate() = foreach(c -> empty!(c.resident), values(_ctx))
 
 # Is `a` (a host array) what the device already holds under `name`?  Same address and size, and -- unless CPM_TRUST_UNCHANGED --
-# the same content: one pass over the array (a wrapping UInt64 sum of its words; ~10 GB/s, far below the cost of the PCIe
-# upload + table build it saves), so an array edited in place is uploaded again.
-_stamp(a::Array{Float64}) = (UInt(pointer(a)), size(a), _trust() ? UInt64(0) : reduce(+, reinterpret(UInt64, vec(a)); init=UInt64(0)))
+# the same content: one pass over the array that depends on WHERE every word sits (a wrapping UInt64 sum of the words and a
+# wrapping sum of word x (2 x position + 1): an edit in place changes it, and so does a permutation in place -- two zones' rows
+# swapped, a sort --, which a plain sum would not see).  Far below the cost of the PCIe upload + table build it saves.
+function _fingerprint(a::Array{Float64})
+    w = reinterpret(UInt64, vec(a))
+    plain = UInt64(0); weighted = UInt64(0)
+    @inbounds for i in eachindex(w)
+        plain += w[i]
+        weighted += w[i] * (UInt64(2) * UInt64(i - 1) + UInt64(1))
+    end
+    (plain, weighted)
+end
+_stamp(a::Array{Float64}) = (UInt(pointer(a)), size(a), (_trust() ? (UInt64(0), UInt64(0)) : _fingerprint(a))...)
 function _ensure(upload::Function, c::Ctx, name::Symbol, a::Array{Float64})
     s = _stamp(a)
     if get(c.resident, name, nothing) != s

@@ -42,7 +42,7 @@ int main(int argc, char **argv)
                              (void *)cpm_init_states_strided, (void *)cpm_set_state, (void *)cpm_get_state, (void *)cpm_solve_ivp,
                              (void *)cpm_resample, (void *)cpm_resample_dev, (void *)cpm_solve_ivp_async, (void *)cpm_synth_tables,
                              (void *)cpm_synth_tables_skewed, (void *)cpm_last_kernel_ms, (void *)cpm_algorithmic_bytes_per_hour,
-                             (void *)cpm_debug_categorical};
+                             (void *)cpm_debug_categorical, (void *)cpm_synth_datamatrix, (void *)cpm_refresh_tables};
         size_t n = sizeof fns / sizeof fns[0], ok = 0;
         for (size_t i = 0; i < n; ++i) ok += fns[i] != NULL;
         printf("symbols %zu of %zu, version %d\n", ok, n, (int)cpm_version());

@@ -355,11 +355,13 @@ def test_headline_config_full_size(cpm, O):
         assert np.array_equal(pk, ref["parking"])
 
 
-def test_melbourne_shaped_config(cpm, O):
-    """BASELINE.json configs[1] shape (Z = 2,357 zones; here 200 cars/zone to keep the oracle quick):
-    sparse Melbourne-shaped datamatrix -> createpdrive / createpdestin on the device -> IVP ->
-    resample with travel times, against the oracle run on the tables the device returned."""
-    Z, T, cpz = 2357, 24, 200
+@pytest.mark.parametrize("cpz", [100, 200])
+def test_melbourne_shaped_config(cpm, O, cpz):
+    """BASELINE.json configs[0] (100 cars/zone: the reference's own CPU-runnable case, main.jl:41 -- AUTO's one-car-per-thread
+    instantiation of the grouped path at full Z) and configs[1]'s shape (here 200 cars/zone to keep the oracle quick; the full
+    1,000 are in tests/test_full_size.py): sparse Melbourne-shaped datamatrix -> createpdrive / createpdestin on the device ->
+    IVP -> resample with travel times, against the oracle run on the tables the device returned."""
+    Z, T = 2357, 24
     C = Z * cpz
     dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED)
     with cpm.Sampler(Z, T) as s:
@@ -372,6 +374,7 @@ def test_melbourne_shaped_config(cpm, O):
         ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
         s.init_states(C, cpz)
         assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
+        assert s.get_info(1) == 5                          # AUTO runs the grouped path at both fleet sizes
         r = s.resample(SIM_SEED, travel=True)
     assert np.array_equal(r["parking"], ref["parking"])
     assert np.array_equal(r["driving"], ref["driving"])
@@ -439,6 +442,42 @@ def test_rccl_allreduce_on_the_sampler_stream(cpm):
         assert st["cars_per_hour_ok"]
         assert (st["parking"], st["driving"]) == want[SIM_SEED + (st["k"] & 1)], st["k"]
     assert (out["sync"]["parking"], out["sync"]["driving"]) == want[SIM_SEED]
+
+
+@pytest.mark.parametrize("deal", ["interleaved", "contiguous"])
+def test_two_hip_ranks_on_one_gpu_sum_to_the_single_run(cpm, deal):
+    """The sharded path with HIP ranks side by side: two processes, each with its own context on the one GPU and its share of the
+    fleet, counts summed over gloo (tests/hip_world2.py) -- the sums must be the single-context run's, for both deals (Philox is
+    keyed by the global car id; src/resampling.jl:11-83 reads only car i's row)."""
+    import hashlib
+    import json
+    import socket
+    import subprocess
+    import sys
+    Z, cpz, T, world = 384, 250, 24, 2
+    C = Z * cpz
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "hip_world2.py"), str(r), str(world), str(port), str(Z), str(cpz),
+                               hex(TABLE_SEED), hex(SIM_SEED), deal], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so_, se_) in zip(procs, outs):
+        assert p.returncode == 0, so_[-2000:] + se_[-4000:]
+    out = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["backend"] == "gloo" and out["world"] == world and sum(out["counts"]) == C and min(out["counts"]) > 0
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        for k, st in enumerate(out["steps"]):
+            r = s.resample(SIM_SEED + k)
+            assert st["cars_per_hour_ok"] and st["own_cars_ok"]
+            assert st["parking"] == hashlib.sha256(r["parking"].tobytes(order="F")).hexdigest(), (deal, k)
+            assert st["driving"] == hashlib.sha256(r["driving"].tobytes(order="F")).hexdigest(), (deal, k)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -597,6 +636,75 @@ def test_high_word_search_equals_the_f64_search_on_ties_and_edges(cpm, O):
             assert np.array_equal(got, want), (o, np.flatnonzero(got != want)[:5])
             total_exact += n_exact
         assert total_exact > 1000  # the fallback really ran
+
+
+def test_unnormalised_weights_and_row_sums_give_the_same_tables(cpm, O):
+    """cpm_build_p_dest without a host copy keeps createpdestin's WEIGHTS and their row sums on the device and divides where an
+    entry is read (k_build_rows, search_exact_ckpt) -- the CDF rows, the packs and the tie fallback must be those of the
+    normalised table (src/createpdestin.jl:38-46 then src/resampling.jl:39).  Checked row by row against the oracle's
+    createpdestin + sequential sum, with draws on, below and above every breakpoint (ties go through the checkpoint walk)."""
+    Z, T = 333, 24
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.3)
+    dm[7, :, :, :] = 0.0                      # an origin without data: all-zero rows
+    dm = np.asfortranarray(dm)
+    rng = np.random.default_rng(5)
+    with cpm.Sampler(Z, T) as s:
+        s.set_datamatrix(dm, dist)
+        s.build_p_drive(0.1, 0.9, 0.5, want=False)
+        for e_dest in (2, 0.5):
+            s.build_p_dest(e_dest, want=False)            # weights + row sums stay on the device
+            p = O.createpdestin(dm, Z, T, e_dest)
+            total_exact = 0
+            for (o, t) in [(1, 1), (8, 3), (Z, T), (100, 12), (257, 24)]:
+                want_cdf = np.cumsum(p[o - 1, :, t - 1])
+                cdf = s.get_cdf_row(o, t)                 # (built on first need from the same weights and sums)
+                if isinstance(e_dest, int):
+                    assert np.array_equal(cdf, want_cdf), (o, t)
+                else:
+                    np.testing.assert_allclose(cdf, want_cdf, rtol=1e-12, atol=0)
+                t53 = np.floor(np.minimum(cdf, 1.0 - 2.0 ** -53) * 2.0 ** 53).astype(np.int64)
+                k53 = np.concatenate([np.clip(t53 + d, 0, 2 ** 53 - 1) for d in (-2 ** 21, -1, 0, 1, 2 ** 21)] +
+                                     [rng.integers(0, 2 ** 53, size=3000)]).astype(np.uint64)
+                got, n_exact = s.debug_categorical(o, t, k53)
+                assert np.array_equal(got, _ref_categorical(cdf, k53)), (e_dest, o, t)
+                total_exact += n_exact
+            assert total_exact > 500
+
+
+def test_refresh_tables_and_lazy_cdf_rows(cpm, O):
+    """The f64 CDF rows are built on first need (car / exact-layout kernels, cpm_get_cdf_row) or with the packs
+    (cpm_refresh_tables(with_f64_cdf)); either way they are the sequential sums, and a refresh changes no result."""
+    Z, T, cpz = 130, 5, 40
+    C = Z * cpz
+    p_drive = O.synth_p_drive(Z, T, TABLE_SEED)
+    p_dest = O.synth_p_dest_dense(Z, T, TABLE_SEED)
+    cdf = O.build_cdf(p_dest)
+    ref = O.fast_run(p_drive, cdf, C, SIM_SEED, _zone0(C, cpz))
+    with cpm.Sampler(Z, T) as s:
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED)
+        r0 = s.resample(SIM_SEED)                          # grouped path: no f64 rows yet
+        for full in (True, False, True):
+            s.refresh_tables(with_f64_cdf=full)
+            for (o, t) in [(1, 1), (Z, T), (64, 3)]:
+                assert np.array_equal(s.get_cdf_row(o, t), cdf[t - 1, o - 1])
+            for kernel in (0, 1, 2, 5):
+                s.set_kernel(kernel)
+                r = s.resample(SIM_SEED)
+                assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (full, kernel)
+        assert np.array_equal(r0["parking"], ref["parking"])
+
+
+def test_device_synth_datamatrix_equals_the_oracle(cpm, O):
+    Z, T = 97, 24
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED)
+    with cpm.Sampler(Z, T) as s:
+        s.synth_datamatrix(TABLE_SEED)
+        assert np.array_equal(s.get_datamatrix(), dm)
+        assert np.array_equal(s.get_distance(), dist)
+        assert np.array_equal(s.build_p_dest(2), O.createpdestin(dm, Z, T, 2))
 
 
 def test_high_word_table_rows_longer_than_a_power_of_two(cpm, O):

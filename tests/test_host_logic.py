@@ -138,6 +138,24 @@ def test_host_array_stamp_sees_in_place_edits(cpm):
         assert R._stamp(a) != s0, idx
         a[idx] = b
     assert R._stamp(a) == s0
+    # permutations in place keep every word (a plain sum of the words would not change): two zones' rows swapped, a slab sorted
+    a[[3, 7]] = a[[7, 3]]
+    assert R._stamp(a) != s0
+    a[[3, 7]] = a[[7, 3]]
+    assert R._stamp(a) == s0
+    keep = a[:, :, 5].copy()
+    a[:, :, 5] = np.sort(keep, axis=0)
+    assert R._stamp(a) != s0
+    a[:, :, 5] = keep
+    assert R._stamp(a) == s0
+    big = np.asfortranarray(rng.random((3, 1 << 20)))      # several chunks of the fingerprint: words swapped across a chunk border
+    b0 = R._stamp(big)
+    flat = big.reshape(-1, order="A")
+    i, j = (1 << 20) - 1, (1 << 20) + 5
+    flat[i], flat[j] = flat[j], flat[i]
+    assert R._stamp(big) != b0
+    flat[i], flat[j] = flat[j], flat[i]
+    assert R._stamp(big) == b0
     assert R._stamp(a.copy(order="F"))[0] != s0[0]       # another buffer: another address
     R.params.trust_unchanged = True
     try:

@@ -137,6 +137,49 @@ def test_two_sampler_contexts_in_flight_give_the_same_points(cpm, O):
     assert all(r["hours_hold_all_cars"] for r in two)
 
 
+@pytest.mark.gpu
+def test_pipelined_points_that_overflow_are_evaluated_again(cpm, O):
+    """A datamatrix whose trips all end in 6 of 192 zones: those buckets hold ~30 x the mean, the bucket regions (4 x) overflow, and
+    the asynchronous steps of the pipelined sweep come back with their status word set.  Evaluator.finish() then evaluates the
+    point again through the blocking call (which grows the regions) -- the results must be those of a blocking sweep on a fresh
+    context, and the fallbacks are counted."""
+    from carparkingmaps_amd import model_selection as ms
+    Z, cpz = 192, 120
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.9)
+    dm[:, 6:, :, :] = 0.0
+    dm = np.asfortranarray(dm)
+    grid = [ms.Point(a, 0.1, b, d) for d in (2, 1) for a in (0.5, 2.0) for b in (0.8, 1.0)]
+    def lane():
+        s = cpm.Sampler(Z, T)
+        s.set_datamatrix(dm, dist)
+        s.build_p_drive(0.1, 0.9, 0.5, want=False)
+        s.build_p_dest(2, want=False)
+        s.init_states(C, cpz)                        # the initial placement (no IVP: its blocking call would grow the regions already):
+        return s                                     # mean-sized buckets, default regions ...
+    s1 = lane()
+    try:
+        ev = ms.Evaluator(s1, C, SIM_SEED, travel=True)
+        assert s1.get_info(2) == 4
+        piped = ms.grid_sweep(ev, grid, checksums=True)   # ... which the first resample hour overflows
+        assert ev.fallbacks >= 1 and sum(r["fallback"] for r in piped) == ev.fallbacks
+        assert s1.get_info(2) > 4 or s1.get_info(1) == 2
+    finally:
+        s1.close()
+    s2 = lane()
+    try:
+        ev2 = ms.Evaluator(s2, C, SIM_SEED, travel=True)
+        blocking = [ev2.evaluate(pt) for pt in grid]
+    finally:
+        s2.close()
+    import zlib
+    for a, pt, b in zip(piped, grid, blocking):
+        assert a["A_drive"] == b["A_drive"], pt
+        assert a["parking_crc32"] == zlib.crc32(np.ascontiguousarray(b["parking"].ravel(order="F")).tobytes()), pt
+        assert a["driving_crc32"] == zlib.crc32(np.ascontiguousarray(b["driving"].ravel(order="F")).tobytes()), pt
+        assert a["hours_hold_all_cars"]
+
+
 def test_lanes_cover_the_ranks_slice_once_and_in_turn():
     """grid_sweep's lane logic without a GPU: stub Evaluators that record the order of begin / finish."""
     from carparkingmaps_amd import model_selection as ms
