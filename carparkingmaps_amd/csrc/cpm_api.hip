@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -72,11 +73,9 @@ struct cpm_ctx {
     bool have_stream = false;
     // tables
     double *d_pdrive = nullptr;  // [T][Z]
-    double *d_p = nullptr;       // [T][Z dest][Z origin] p_destin as the reference lays it out (cpm_set_p_dest, the synthetic tables), or
-                                 // createpdestin's unnormalised weights with their row sums in d_nf (cpm_build_p_dest).  Resident: the row
-                                 // tables below are derived from it in one pass (k_build_rows), ties walk it (search_exact_ckpt)
-    double *d_nf = nullptr;      // [T][Z] row sums of d_p while have_nf (an entry is then d_p / d_nf where d_nf > 0)
-    bool have_nf = false;
+    double *d_p = nullptr;       // [T][Z dest][Z origin] p_destin as the reference lays it out (cpm_set_p_dest, cpm_build_p_dest, the synthetic
+                                 // tables).  Resident: the row tables below are derived from it in one pass (k_build_rows), ties walk it
+                                 // (search_exact_ckpt)
     double *d_cdf = nullptr;     // [T][Z][Zp] canonical f64 CDF rows: built on first need (ensure_full_cdf) -- the car and exact-layout
     bool cdf_full = false;       // kernels and cpm_get_cdf_row read them, the grouped path never does
     uint32_t *d_hi = nullptr;    // [T][Z][RW] row packs: guide + high words of the CDF (cpm_grouped.h)
@@ -203,13 +202,13 @@ hipError_t launch_build_rows(cpm_ctx *c)
         if (c->device >= 0 && c->device < 64) attr_done[c->device] = true;
     }
     dim3 grid(nblk(c->Z, cpm::kRowTile), static_cast<unsigned>(c->T));
-    hipLaunchKernelGGL((cpm::k_build_rows<CDF, PACK>), grid, dim3(cpm::kRowBlock), cpm::kRowLds, c->stream, c->d_p, c->have_nf ? c->d_nf : nullptr,
-                       CDF ? c->d_cdf : nullptr, PACK ? c->d_hi : nullptr, c->d_last, c->d_ckpt, static_cast<int>(c->Z), c->Zp, c->Zq,
+    hipLaunchKernelGGL((cpm::k_build_rows<CDF, PACK>), grid, dim3(cpm::kRowBlock), cpm::kRowLds, c->stream, c->d_p, CDF ? c->d_cdf : nullptr,
+                       PACK ? c->d_hi : nullptr, c->d_last, c->d_ckpt, static_cast<int>(c->Z), c->Zp, c->Zq,
                        cpm::pack_guide_bits(static_cast<int>(c->Z)), c->d_err);
     return hipGetLastError();
 }
 
-// The table in d_p (+ d_nf) -> everything the samplers read: row totals, checkpoints and -- when a row pack fits LDS -- the row packs
+// The table in d_p -> everything the samplers read: row totals, checkpoints and -- when a row pack fits LDS -- the row packs
 // of the grouped path, in one pass.  The f64 CDF rows are built with them only when no pack fits (then every kernel searches f64
 // rows) or when the caller asks; otherwise on first need (ensure_full_cdf).
 int32_t build_rows(cpm_ctx *c, bool with_cdf)
@@ -292,7 +291,6 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
     tb.thr = c->d_thr;
     tb.ckpt = c->d_ckpt;
     tb.p = c->d_p;
-    tb.nf = c->have_nf ? c->d_nf : nullptr;
     tb.tt = c->d_tt;
     tb.Z = static_cast<int>(c->Z);
     tb.Zp = c->Zp;
@@ -371,6 +369,17 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
 
 int32_t finish_ivp(cpm_ctx *c);
 
+// What a non-zero status word of a grouped step asks of the context.  Bit 2 (4): a placing block of the fused hour gave up waiting
+// for its sampler workgroups (a dispatch order the hand-off did not expect): two launches per hour from now on.  Bit 1 (2): a bucket
+// region or a run overflowed: twice the regions while the problem still fits.  true: the step can be repeated on the grouped path.
+bool absorb_status(cpm_ctx *c, long long st)
+{
+    bool again = (st & 4) != 0;
+    if (again) c->zg.fused_ok = false;
+    if ((st & ~4ll) != 0) again = grow_grouped(c);
+    return again;
+}
+
 int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_counts)
 {
     if (!c->have_pdrive || !c->have_cdf) return fail(CPM_ERR_STATE, "resample: p_drive / p_dest not set");
@@ -384,7 +393,7 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     size_t nwords = static_cast<size_t>(2 * c->T * c->Z + 2);
     if (c->status_pending && hipEventQuery(c->status_ev) == hipSuccess) {
         c->status_pending = false;
-        if (c->h_status[0] != 0 && !grow_grouped(c)) c->grouped_overflowed = true;
+        if (c->h_status[0] != 0 && !absorb_status(c, c->h_status[0])) c->grouped_overflowed = true;
         c->zg.set_parts(static_cast<uint32_t>(c->h_status[1]), static_cast<uint32_t>(c->h_status[1] >> 32));
     }
     const int kernel = pick_kernel(c);
@@ -484,7 +493,7 @@ int32_t finish_ivp(cpm_ctx *c)
     }
     // A bucket or a run outgrew its region: d_zone0 is untouched.  Run the IVP again with twice the regions while the problem
     // still fits, else on the exact layout (and stay there).
-    while (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
+    while (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && absorb_status(c, c->h_ivp_status[0])) {
         int32_t rc = ivp_grouped(c, c->ivp_seed);
         if (rc != CPM_OK) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -583,6 +592,9 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
+    // development switches (tools/, A/B runs): the defaults of CPM_OPT_FUSED / CPM_OPT_FUSED_LAG
+    if (const char *v = std::getenv("CPM_FUSED")) c->zg.fused_ok = std::atoi(v) != 0;
+    if (const char *v = std::getenv("CPM_FUSED_LAG")) c->zg.fused_lag = std::max(1, std::min(64, std::atoi(v)));
     *ctx_out = c;
     return CPM_OK;
 }
@@ -595,7 +607,6 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_pdrive);
     dfree(c->d_cdf);
     dfree(c->d_p);
-    dfree(c->d_nf);
     dfree(c->d_ckpt);
     dfree(c->d_hi);
     dfree(c->d_last);
@@ -629,6 +640,15 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         if (value != CPM_KERNEL_AUTO && value != CPM_KERNEL_CAR && value != CPM_KERNEL_ZONE_LDS && value != CPM_KERNEL_ZONE_GROUPED) return fail(CPM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = static_cast<int>(value);
         return CPM_OK;
+    case CPM_OPT_FUSED:
+        if (value < 0 || value > 2) return fail(CPM_ERR_ARG, "fused hour %lld", (long long)value);
+        c->zg.fused_ok = value != 0;
+        c->zg.fused_spin = value == 2 ? 0u : cpm::kFusedSpinLimit;  // 2: the placing blocks give up at once (tests of the bail-out)
+        return CPM_OK;
+    case CPM_OPT_FUSED_LAG:
+        if (value < 1 || value > 64) return fail(CPM_ERR_ARG, "fused lag %lld", (long long)value);
+        c->zg.fused_lag = static_cast<int>(value);
+        return CPM_OK;
     case CPM_OPT_PROFILE_KERNEL:
         if (value < CPM_PROFILE_SAMPLER || value > CPM_PROFILE_TRAVEL) return fail(CPM_ERR_ARG, "profile kernel %lld", (long long)value);
         c->prof_what = static_cast<int>(value);
@@ -656,6 +676,12 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         return CPM_OK;
     case CPM_INFO_PARTS:
         *value_out = c->zg.parts;
+        return CPM_OK;
+    case CPM_INFO_FUSED:
+        *value_out = (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zg.fused_ok && c->zg.parts <= 1 &&
+                      cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z))))
+                         ? 1
+                         : 0;
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown info %d", what);
@@ -716,7 +742,6 @@ int32_t cpm_set_p_dest(cpm_ctx *c, const double *p_dest)
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
     if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
     c->have_cdf = false;
-    c->have_nf = false;
     HIP_TRY(hipMemcpyAsync(c->d_p, p_dest, bytes, hipMemcpyHostToDevice, c->stream));
     return build_rows(c, false);  // (synchronises: the validation flag is read back)
 }
@@ -966,26 +991,18 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
     }
     if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
-    // createpdestin's weights in the reference's layout + their row sums; the division (:38-46) happens where an entry is read.
-    // Both stay with the context (a sweep calls this entry once per e_dest value: no allocation on that path).
+    // createpdestin's array in the reference's layout: weights, then normalised in place.  It stays with the context (a sweep calls
+    // this entry once per e_dest value: no allocation on that path); the row tables are derived from it in one more pass.
     if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
-    if (!c->d_nf) HIP_TRY(hipMalloc(&c->d_nf, sizeof(double) * c->Z * c->T));
     c->have_cdf = false;
     dim3 g1(nblk(c->Z, 256), static_cast<unsigned>(c->Z));
     if (c->T == 24)
         hipLaunchKernelGGL(cpm::k_pdest_weights<24>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
     else
         hipLaunchKernelGGL(cpm::k_pdest_weights<0>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
-    hipLaunchKernelGGL(cpm::k_pdest_rowsum, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_p, c->d_nf, static_cast<int>(c->Z));
+    hipLaunchKernelGGL(cpm::k_pdest_normalise, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_p, static_cast<int>(c->Z));
     hipError_t e = hipGetLastError();
-    c->have_nf = true;
-    if (e == hipSuccess && out) {  // createpdestin's array for the host: normalised in place, the row sums are spent
-        hipLaunchKernelGGL(cpm::k_pdest_divide, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream,
-                           c->d_p, c->d_nf, static_cast<int>(c->Z));
-        e = hipGetLastError();
-        c->have_nf = false;
-        if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_p, bytes, hipMemcpyDeviceToHost, c->stream);
-    }
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_p, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));
     return build_rows(c, false);  // (synchronises)
 }
@@ -1038,7 +1055,6 @@ int32_t cpm_synth_tables_skewed(cpm_ctx *c, uint64_t table_seed, int64_t skew_q)
     c->have_pdrive = true;
     if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, sizeof(double) * c->Z * c->Z * c->T));
     c->have_cdf = false;
-    c->have_nf = false;
     dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
     hipLaunchKernelGGL(cpm::k_synth_p_dest, grid, dim3(64), 0, c->stream, c->d_p, static_cast<int>(c->Z), table_seed, skew_q);
     HIP_TRY(hipGetLastError());
@@ -1217,7 +1233,7 @@ int32_t cpm_resample(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *parking
     };
     if (rc == CPM_OK) rc = fetch();
     // a bucket or a run outgrew its region: again with twice the regions while the problem still fits ...
-    while (rc == CPM_OK && c->h_counts[nwords - 1] != 0 && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grow_grouped(c)) {
+    while (rc == CPM_OK && c->h_counts[nwords - 1] != 0 && pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && absorb_status(c, c->h_counts[nwords - 1])) {
         rc = resample_enqueue(c, seed, flags, c->d_counts);
         if (rc == CPM_OK) rc = fetch();
     }
@@ -1311,7 +1327,7 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
         const size_t th = static_cast<size_t>(hour1 - 1);
         hipLaunchKernelGGL(cpm::k_pack_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
                            c->d_ckpt + th * cpm::ckpt_count(static_cast<int>(c->Z)) * c->Z, c->d_p + th * c->Z * c->Z,
-                           c->have_nf ? c->d_nf + th * c->Z : nullptr, static_cast<int>(origin1 - 1), static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
+                           static_cast<int>(origin1 - 1), static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
         e = hipGetLastError();
     }
     int h_n = 0;

@@ -4,8 +4,11 @@
 // The reference walks p_dest[origin,:,t] once per driving car (src/resampling.jl:34-45).  Here the cars of one origin zone sit
 // together, so the zone's row is streamed from HBM once per hour into LDS and every car of the zone searches it there.
 //
-//   * Fixed-stride buckets: zone z owns ids[z*cap .. z*cap + cnt[z]) (cap = cap_mult x the mean bucket, cap_mult = 4, doubled by the
-//     context after an overflow).  The bucket sizes ARE the parking histogram (src/saveresults.jl:10-12): no histogram atomics.
+//   * Fixed-stride buckets: zone z owns the region ids[z*cap .. (z+1)*cap) (cap = cap_mult x the mean bucket, cap_mult = 4, doubled
+//     by the context after an overflow).  A bucket has two ends: the cars that STAYED in z last hour fill the region from the bottom
+//     (cnt_s[z] of them, written by the zone's own sampler workgroup), the cars that ARRIVED fill it from the top (cnt_a[z], written
+//     by the placing blocks) -- neither writer needs the other's count, so the placing of hour t's drivers does not wait for the
+//     samplers of their destination zones.  cnt_s + cnt_a IS the parking histogram (src/saveresults.jl:10-12): no histogram atomics.
 //   * Row packs: what a workgroup stages is the HIGH WORD of the canonical CDF row (4 B per destination instead of 8) behind a GUIDE
 //     table (cut-point method).  With hi[j] = floor(cdf[j] * 2^32) (0xFFFFFFFF when cdf[j] >= 1) and khi = the high Philox word
 //     = floor(u * 2^32):   hi[j] > khi => cdf[j] >= u   and   hi[j-1] < khi => cdf[j-1] < u,   so the first j with hi[j] >= khi IS
@@ -35,6 +38,7 @@
 namespace cpm {
 
 constexpr int kGroups = 32;              // destination groups
+constexpr int kFusedThreads = 256;       // threads of every block of the fused hour (k_grouped_hour)
 constexpr int kMaxZonesPerGroup = 1024;  // LDS bins of the place kernel
 constexpr uint32_t kHiMax = 0xFFFFFFFFu;
 constexpr int kMaxCapMult = 64;
@@ -150,41 +154,58 @@ __global__ __launch_bounds__(kBucketBlock) void k_bucket_cars(const uint32_t *__
     }
 }
 
-// car-indexed state from fixed-stride buckets (end of the IVP)
-__global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt, uint32_t cap, uint32_t *__restrict__ zone0)
+// car-indexed state from fixed-stride buckets (end of the IVP): both ends of every region; a bucket whose ends met is flagged here
+// (the hour that filled it has no sampler launch behind it to notice)
+__global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt_s, const uint32_t *__restrict__ cnt_a, uint32_t cap,
+                           uint32_t *__restrict__ zone0, unsigned long long *status)
 {
     const uint32_t z = blockIdx.x;
-    const uint32_t n = min(cnt[z], cap);
-    for (uint32_t s = threadIdx.x; s < n; s += blockDim.x) zone0[ids[static_cast<size_t>(z) * cap + s]] = z;
+    const uint32_t ns_raw = cnt_s[z], na_raw = cnt_a[z];
+    const uint32_t ns = min(ns_raw, cap), na = min(na_raw, cap - ns);
+    if (threadIdx.x == 0 && static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(status, 2ull);
+    const uint32_t gap = cap - ns - na;
+    for (uint32_t s = threadIdx.x; s < ns + na; s += blockDim.x) zone0[ids[static_cast<size_t>(z) * cap + s + (s >= ns ? gap : 0u)]] = z;
 }
 
 // ------------------------------------------------------------------------------------------------ hourly sampler
+// What only the rare branches of the hourly kernels read (the exact fallback of a tie, a heavy bucket, an overflow): in device
+// memory, behind ONE pointer of the launch arguments -- the sampler lives at its SGPR limit (106, scalars spilled into VGPR lanes
+// and read back with v_readlane in its hot paths), and nine more pointers in its arguments cost it 6 us per launch.  Written by
+// k_grouped_zero at the start of every run.
+struct GroupedRare {
+    const double *ckpt, *p;               // [T][nck][Z] running-sum checkpoints, [T][Z dest][Z origin] p_destin
+    uint32_t *maxn, *heavy_list, *nheavy; // [2] largest heavy bucket / most heavy buckets of an hour; [hgrid] zones of this hour's heavy launch; [T+1] how many per hour
+    unsigned long long *status;           // the status word of the run's count tensor
+    uint32_t hgrid, parts;                // zones the heavy launch covers, workgroups per heavy zone (GroupedWork)
+    int Z, pad_;
+};
+
 struct GroupedArgs {
-    const uint32_t *ids;      // [Z*cap] this hour's buckets (local car indices)
-    const uint32_t *cnt;      // [Z] their sizes
+    const uint32_t *ids;      // [Z*cap] this hour's buckets (local car indices): stayers from the bottom of a zone's region, arrivals from its top
+    const uint32_t *cnt_s;    // [Z] stayers per bucket
+    const uint32_t *cnt_a;    // [Z] arrivals per bucket
     const uint32_t *rp_t;     // [Z][RW] row packs of this hour
     const double *last_t;     // [Z] row totals (f64)
     const long long *thr_t;   // [Z] Bernoulli thresholds floor(p_drive * 2^53) of this hour
-    const double *ckpt_t;     // [nck][Z] every 32nd value of this hour's running sums (exact fallback: search_exact_ckpt)
-    const double *p_t;        // [Z dest][Z origin] this hour's slab of p_destin as the reference lays it out
-    const double *nf_t;       // [Z] its row normalisers, or null when the table is normalised already
+    const GroupedRare *rare;  // tables of the exact fallback, heavy-bucket bookkeeping, status word
     uint32_t *ids_next;       // [Z*cap]  next hour's buckets: the stayers (grouped) / dest | drive << 31 per slot (plain)
-    uint32_t *cnt_next;       // [Z] stayers (grouped; k_grouped_place adds the arrivals)
+    uint32_t *cnt_next;       // [Z] next hour's stayers (grouped); the arrivals are counted by k_grouped_place, in an array of their own
     uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
     uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
-    unsigned long long *parking_t, *driving_t, *status;
-    uint32_t *maxn;           // [2] what the context sizes the heavy launch from: the largest heavy bucket, the most heavy buckets in one hour
-    uint32_t *heavy_list;     // [hgrid] zones whose bucket this launch has handed to k_grouped_sample_heavy
-    uint32_t *nheavy_t;       // how many (this hour)
-    uint32_t hgrid;           // zones the heavy launch behind this one covers (its grid.x)
-    int Z, Zp, Zq, G;
+    unsigned long long *parking_t, *driving_t;
+    int Z, Zq, G;
+    int hour;                 // table hour of this launch (0-based): rare->nheavy[hour] counts its heavy buckets
+    uint32_t *done_t;         // fused hour: [chunks] sampler workgroups of every chunk of origin zones that have handed their runs over
+    int lag;                  // fused hour: the placing blocks of chunk j sit behind the sampler workgroups of chunk j + lag
+    uint32_t spin_limit;      // fused hour: polls a placing block makes before it gives up (0: at once -- the tests' way into the bail-out)
     uint32_t cap, scap, idbits, gshift, step;
-    uint32_t parts;           // 1: this launch walks whole buckets (overflow rounds of BLOCK cars).  > 1: of a HEAVY bucket (more than
-                              // kHeavy * CPT * BLOCK cars) that gets a place in heavy_list it takes the first CPT * BLOCK cars only;
-                              // k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest
+    // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
+    //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
+    //  k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest)
     CarIndex cars;
     uint64_t seed;
 };
+
 
 // A barrier for LDS data only: this wave's LDS operations have completed, then the workgroup meets.  __syncthreads() is also a
 // workgroup-scope fence, for which hipcc waits until the wave's global stores and ATOMICS have completed (s_waitcnt vmcnt(0)) -- a
@@ -206,8 +227,7 @@ __device__ __forceinline__ uint32_t from_lane0(uint32_t v) { return static_cast<
 
 // ------------------------------------------------------------------------------------------------ row tables in ONE pass
 // Everything the samplers read of p_destin is derived here from the table as the reference lays it out, p[o + Z*(d + Z*t)]
-// (origin fastest; `nf` != null: the table holds createpdestin's unnormalised weights and an entry is p / nf[t][o] where nf > 0,
-// src/createpdestin.jl:38-46), in one pass over it:
+// (origin fastest), in one pass over it:
 //   * the running sum of a row, left to right in f64 -- range_up = range_up + distribution[j] of src/resampling.jl:39; a tree scan
 //     would move boundaries by ulps -- by ONE lane per origin (the 64 origins of a tile are 64 consecutive words of p: coalesced);
 //   * CDF && cdf  : the canonical CDF rows cdf[t][o][d] (f64, padded with +inf to Zp) -- only for the kernels that search f64 rows
@@ -219,18 +239,116 @@ __device__ __forceinline__ uint32_t from_lane0(uint32_t v) { return static_cast<
 //   * ckpt[t][k][o] = cdf[min(32 k + 31, Z - 1)]: every 32nd value of the running sum.  A tie of the high-word search repeats the
 //                   reference's walk from the checkpoint in front of it (search_exact_ckpt): at most 32 sequential additions of the
 //                   same p entries, bit-identical to the full running sum, without 8 bytes per destination in HBM.
-// Block = 5 waves: wave 0 sums (64 loads in flight per lane), waves 1-4 take the 64 x 64 tile it leaves in LDS (two buffers, one
-// barrier per tile) and write it out row-major: consecutive lanes, consecutive destinations of one row.
+// Block = 4 waves: wave 0 sums (32-64 loads in flight per lane), waves 1-3 take the 64 x 64 tile it leaves in LDS (two buffers, one
+// barrier per tile) and write it out row-major: consecutive lanes, consecutive destinations of one row.  Two blocks per CU (LDS), two
+// waves per SIMD: the summing wave may use 256 VGPRs (its two half tiles in flight are 128 of them; with the 168 of three waves per
+// SIMD hipcc spilled the destinations of the hand-written loads -- before their data had landed).
 // (Round 2 built the same in three launches -- CDF, high words from the CDF just written, guide by a binary search per entry over the
 // high words just written -- 13.4 GB of traffic for the 8.3 GB one pass needs, 3.77 ms at S4k.)
 constexpr int kRowTile = 64;
-constexpr int kRowBlock = 320;
+constexpr int kRowBlock = 256;
 constexpr int kCkptStride = 32;
 __host__ __device__ inline int ckpt_count(int Z) { return (Z + kCkptStride - 1) / kCkptStride; }
 constexpr size_t kRowLds = sizeof(double) * 2 * kRowTile * (kRowTile + 1) + sizeof(uint32_t) * kRowTile;
 
+// The summing wave of k_build_rows: lane = origin.  Tiles that lie wholly inside the row take the pipelined path: one half tile of
+// 32 loads is always in flight behind the one being added up.  The loads are buffer loads -- descriptor on the tile's first row,
+// the row's byte offset in a scalar register, the lane's 8-byte offset in ONE VGPR: with plain pointers hipcc built the 64 row
+// addresses of a tile as 64-bit VGPR chains and spilled, and a predicated load among them made it wait vmcnt(0), so that a half
+// tile's loads no longer overlapped the other half's additions (3.3 ms at S4k).  Unconditional and of one kind, hipcc counts them
+// itself (s_waitcnt vmcnt(32), 31, ... in front of the additions).  The last one or two tiles (the row's end and the pad) take a
+// plain path: rows beyond the table are clamped to its last row and their values unused.
+typedef uint32_t cpm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double row_load(__amdgpu_buffer_rsrc_t rows, uint32_t lane_off, uint32_t row_off)
+{
+    const cpm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rows, lane_off, row_off, 0);
+    return __hiloint2double(static_cast<int>(v.y), static_cast<int>(v.x));
+}
+
+__device__ __forceinline__ void row_sums(double (*tile)[kRowTile][kRowTile + 1], const double *__restrict__ src, int lane, bool live,
+                                         double *__restrict__ ck, double *__restrict__ last_o, int Z, int nt, int *err)
+{
+    constexpr int H = kRowTile / 2;
+    const uint32_t lane_off = static_cast<uint32_t>(live ? lane : 0) << 3;
+    const size_t Zs = static_cast<size_t>(Z);
+    const uint32_t rowb = static_cast<uint32_t>(Z) * 8u;  // bytes between consecutive destinations of one origin
+    double run = 0.0;
+    bool bad = false;
+    double xa[H], xb[H];
+    auto window = [&](const double *row0) {  // (2 tiles of rows: 128 x Z x 8 B < 2^32)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(row0), 0, static_cast<int>(2 * kRowTile * rowb), 0x00020000);
+    };
+    auto sums = [&](double(&x)[H], int buf, int jbase, double *ck_slot) {
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            bad |= !(x[u] >= 0.0);
+            run = run + x[u];
+            tile[buf][lane][jbase + u] = run;
+        }
+        if (ck_slot && live) *ck_slot = run;  // every 32nd value of the running sum
+    };
+    const int nfull = Z / kRowTile;  // tiles wholly inside [0, Z)
+    const double *row0 = src;
+    __amdgpu_buffer_rsrc_t rows = window(row0);
+    if (nfull > 0) {
+#pragma unroll
+        for (int u = 0; u < H; ++u) xa[u] = row_load(rows, lane_off, static_cast<uint32_t>(u) * rowb);
+    }
+    // (the last whole tile is peeled off: inside the loop the prefetch of the next tile is unconditional, so the waits hipcc
+    //  counts in front of the second half's additions leave it in flight)
+#pragma unroll 1
+    for (int k = 0; k + 1 < nfull; ++k) {
+#pragma unroll
+        for (int u = 0; u < H; ++u) xb[u] = row_load(rows, lane_off, static_cast<uint32_t>(H + u) * rowb);
+        sums(xa, k & 1, 0, ck ? ck + static_cast<size_t>(2 * k) * Zs : nullptr);
+#pragma unroll
+        for (int u = 0; u < H; ++u) xa[u] = row_load(rows, lane_off, static_cast<uint32_t>(kRowTile + u) * rowb);
+        sums(xb, k & 1, H, ck ? ck + static_cast<size_t>(2 * k + 1) * Zs : nullptr);
+        lds_barrier();  // (LDS only: the loads of the next tile stay in flight)
+        row0 += kRowTile * Zs;
+        rows = window(row0);
+    }
+    if (nfull > 0) {
+        const int k = nfull - 1;
+#pragma unroll
+        for (int u = 0; u < H; ++u) xb[u] = row_load(rows, lane_off, static_cast<uint32_t>(H + u) * rowb);
+        sums(xa, k & 1, 0, ck ? ck + static_cast<size_t>(2 * k) * Zs : nullptr);
+        sums(xb, k & 1, H, ck ? ck + static_cast<size_t>(2 * k + 1) * Zs : nullptr);
+        lds_barrier();
+    }
+    if (nfull * kRowTile == Z && live && last_o) *last_o = run;
+    const int tail_row = min(nfull * kRowTile, Z - 1);
+    rows = window(src + static_cast<size_t>(tail_row) * Zs);
+#pragma unroll 1
+    for (int k = nfull; k < nt; ++k) {  // the row's end and the pad (+inf): half tiles one after the other
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int d0 = k * kRowTile + h * H;
+#pragma unroll
+            for (int u = 0; u < H; ++u) xa[u] = row_load(rows, lane_off, static_cast<uint32_t>(min(d0 + u, Z - 1) - tail_row) * rowb);
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const int d = d0 + u;
+                double v = __builtin_huge_val();
+                if (d < Z) {
+                    bad |= !(xa[u] >= 0.0);
+                    run = run + xa[u];
+                    v = run;
+                    if (live && (u == H - 1 || d == Z - 1)) {
+                        if (ck) ck[static_cast<size_t>(d / kCkptStride) * Zs] = run;
+                        if (d == Z - 1 && last_o) *last_o = run;
+                    }
+                }
+                tile[k & 1][lane][h * H + u] = v;
+            }
+        }
+        lds_barrier();
+    }
+    if (bad && live) atomicOr(err, 1);
+}
+
 template <bool CDF, bool PACK>
-__global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__restrict__ p, const double *__restrict__ nf, double *__restrict__ cdf,
+__global__ __launch_bounds__(kRowBlock, 2) void k_build_rows(const double *__restrict__ p, double *__restrict__ cdf,
                                                           uint32_t *__restrict__ rp, double *__restrict__ last, double *__restrict__ ckpt,
                                                           int Z, int Zp, int Zq, int G, int *err)
 {
@@ -244,55 +362,12 @@ __global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__res
     const int dmax = PACK ? Zq : Zp;  // (Zq >= Zp)
     const int nt = (dmax + kRowTile - 1) / kRowTile;
     if (wave == 0) {
-        // ---- the running sums: lane = origin
         const int o = o0 + lane;
         const bool live = o < Z;
         const double *src = p + static_cast<size_t>(t) * Z * Z + o0;  // (wave-uniform: a load is scalar row base + the lane's 8-byte offset)
-        const int lane_c = live ? lane : 0;
-        double nfv = 0.0;
-        if (nf != nullptr && live) nfv = nf[static_cast<size_t>(t) * Z + o];
-        const bool div = nfv > 0;  // (NaN: false -- the row stays as it is, src/createpdestin.jl:40)
-        const int nck = ckpt_count(Z);
-        double *ck = ckpt ? ckpt + static_cast<size_t>(t) * nck * Z + o : nullptr;
-        double run = 0.0;
-        bool bad = false;
-        constexpr int H = kRowTile / 2;
-        double xa[H], xb[H];
-        auto load_half = [&](double(&x)[H], int dbase) {
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                const int d = dbase + u;
-                x[u] = (d < Z) ? (src + static_cast<size_t>(d) * Z)[lane_c] : 0.0;
-            }
-        };
-        auto consume_half = [&](double(&x)[H], int dbase, int buf, int jbase) {
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                const int d = dbase + u;
-                double v = __builtin_huge_val();
-                if (d < Z) {
-                    const double y = div ? x[u] / nfv : x[u];
-                    bad |= !(y >= 0.0);
-                    run = run + y;
-                    v = run;
-                    if (live && (u == H - 1 || d == Z - 1)) {  // (32 | dbase: u == 31 is every 32nd destination)
-                        if (ck) ck[static_cast<size_t>(d / kCkptStride) * Z] = run;
-                        if (d == Z - 1 && last) last[static_cast<size_t>(t) * Z + o] = run;
-                    }
-                }
-                tile[buf][lane][jbase + u] = v;
-            }
-        };
-        load_half(xa, 0);
-        for (int k = 0; k < nt; ++k) {
-            const int d0 = k * kRowTile;
-            load_half(xb, d0 + H);
-            consume_half(xa, d0, k & 1, 0);
-            if (k + 1 < nt) load_half(xa, d0 + kRowTile);
-            consume_half(xb, d0 + H, k & 1, H);
-            lds_barrier();  // (LDS only: the loads of the next tile stay in flight)
-        }
-        if (bad && live) atomicOr(err, 1);
+        double *ck = ckpt ? ckpt + static_cast<size_t>(t) * ckpt_count(Z) * Z + o : nullptr;
+        double *last_o = last ? last + static_cast<size_t>(t) * Z + o : nullptr;
+        row_sums(tile, src, lane, live, ck, last_o, Z, nt, err);
         return;
     }
     // ---- the tiles out: lane = destination
@@ -311,7 +386,10 @@ __global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__res
                 uint32_t *pack = rp + row * rw;
                 uint32_t h = kHiMax;
                 if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated), +inf in the pad
+#ifndef CPM_ROWS_NO_HI  // (ablation builds, tools/build_variants.sh: what the write-out costs)
                 if (d < Zq) pack[gw + d] = h;
+#endif
+#ifndef CPM_ROWS_NO_GUIDE
                 uint32_t hp = __shfl_up(h, 1, 64);
                 if (lane == 0) hp = prevh[r];
                 if (lane == 63) prevh[r] = h;  // (row r is this wave's in every tile)
@@ -332,6 +410,7 @@ __global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__res
                     const uint16_t v = static_cast<uint16_t>(k * kRowTile + srcl);
                     for (int i = lane; i < cnt; i += 64) guide[s0 + i] = v;
                 }
+#endif
             }
         }
     }
@@ -340,32 +419,53 @@ __global__ __launch_bounds__(kRowBlock, 3) void k_build_rows(const double *__res
 // The categorical draw of src/resampling.jl:38-45 for ONE car on the table itself (ties of the high-word search, draws above the row
 // total): first j with cdf[j] >= ue -- found from the checkpoints (binary search over every 32nd value of the running sum), then the
 // reference's own walk, run = run + p[j], from the checkpoint in front.  Same additions in the same order as the full running sum.
-__device__ __noinline__ uint32_t search_exact_ckpt(const double *__restrict__ ckpt_t, const double *__restrict__ p_t, const double *__restrict__ nf_t,
-                                                   int Z, int o, double uc, double last)
+// hint >= 0: a destination the answer is known not to lie in front of (a tie of the high-word search: every destination below
+// the first one with hi >= khi has cdf < u) -- the walk then starts in the hint's block of 32 without searching the checkpoints.
+// The loads of a batch do not depend on the running sum: eight are requested together (a tie stalls its workgroup for the round
+// trips it takes; with one dependent load per destination the ~2 ties of every hourly launch added microseconds to its tail).
+__device__ __forceinline__ uint32_t search_exact_tables(const double *__restrict__ ckpt_t, const double *__restrict__ p_t, int Z, int o, double uc,
+                                                        double last, int hint)
 {
     const double ue = clamp_u(uc, last);
-    int lo = 0, n = ckpt_count(Z);
-    while (n > 0) {  // first k with ckpt[k] >= ue (the last one is the row total >= ue)
-        const int half = n >> 1;
-        if (ckpt_t[static_cast<size_t>(lo + half) * Z + o] < ue) {
-            lo += half + 1;
-            n -= half + 1;
-        } else {
-            n = half;
+    int k;
+    if (hint >= 0) {
+        k = hint / kCkptStride;
+    } else {
+        int lo = 0, n = ckpt_count(Z);
+        while (n > 0) {  // first k with ckpt[k] >= ue (the last one is the row total >= ue)
+            const int half = n >> 1;
+            if (ckpt_t[static_cast<size_t>(lo + half) * Z + o] < ue) {
+                lo += half + 1;
+                n -= half + 1;
+            } else {
+                n = half;
+            }
+        }
+        k = min(lo, ckpt_count(Z) - 1);
+    }
+    constexpr int kB = 8;
+    double run = k ? ckpt_t[static_cast<size_t>(k - 1) * Z + o] : 0.0;
+    for (int j0 = k * kCkptStride; j0 < Z; j0 += kB) {  // (the running sum carries on across blocks: same additions, same order)
+        double x[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) x[u] = p_t[static_cast<size_t>(min(j0 + u, Z - 1)) * Z + o];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            if (j0 + u < Z) {
+                run = run + x[u];
+                if (run >= ue) return static_cast<uint32_t>(j0 + u);
+            }
         }
     }
-    lo = min(lo, ckpt_count(Z) - 1);
-    double run = lo ? ckpt_t[static_cast<size_t>(lo - 1) * Z + o] : 0.0;
-    const double nfv = nf_t ? nf_t[o] : 0.0;
-    const bool div = nfv > 0;
-    int j = lo * kCkptStride;
-    const int jend = min(j + kCkptStride, Z);
-    for (; j < jend; ++j) {
-        const double x = p_t[static_cast<size_t>(j) * Z + o];
-        run = run + (div ? x / nfv : x);
-        if (run >= ue) break;
-    }
-    return static_cast<uint32_t>(min(j, Z - 1));
+    return static_cast<uint32_t>(Z - 1);
+}
+
+// the exact fallback of one car of the hourly kernels (rare: out of line, reads its tables through the rare block)
+__device__ __noinline__ uint32_t search_exact_ckpt(const GroupedRare *__restrict__ rare, int hour, int o, double uc, double last, int hint)
+{
+    const int Z = rare->Z;
+    const size_t th = static_cast<size_t>(hour);
+    return search_exact_tables(rare->ckpt + th * ckpt_count(Z) * Z, rare->p + th * Z * Z, Z, o, uc, last, hint);
 }
 
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -560,15 +660,47 @@ __device__ unsigned long long *g_place_stamps = nullptr;  // [blocks][8], set by
 #define CPM_PSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
 #endif
 
-template <int BLOCK, int CPT, int NQ, bool GROUPED>
-__global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample(GroupedArgs a)
+// LDS of a sampler workgroup beside the row pack (one object: the fused kernel overlays it with the placing blocks')
+struct SampleLds {
+    uint32_t ndrive, nstay, split;
+    uint32_t gb[kGroups];
+    uint32_t stage[kGroups * kStage];
+};
+
+// A store / load of words that another workgroup of the SAME launch reads / has written (FUSED: the runs and run lengths, handed
+// from the sampler workgroups to the placing blocks of the fused hour): write-through past this XCD's L2 and past the reader's L1
+// (global_store / global_load ... sc1), as MI355X_MICROARCH.md's hand-off table prescribes.  !FUSED: plain.
+template <bool FUSED>
+__device__ __forceinline__ void hand_store(uint32_t *p, uint32_t v)
 {
-    extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
-    __shared__ uint32_t s_ndrive, s_nstay, s_split;
-    __shared__ uint32_t gb[kGroups];
-    __shared__ uint32_t stage[GROUPED ? kGroups * kStage : 1];
+    if constexpr (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool FUSED>
+__device__ __forceinline__ uint32_t hand_load(const uint32_t *p)
+{
+    if constexpr (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+// FUSED: this workgroup's runs are complete -- every storing wave drains its stores, the workgroup meets, ONE lane counts the
+// workgroup in (agent-scope add on the counter of its chunk of origin zones; the placing blocks of that chunk poll it)
+template <bool FUSED>
+__device__ __forceinline__ void hand_off_done(uint32_t *done_chunk, int tid)
+{
+    if constexpr (FUSED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) __hip_atomic_fetch_add(done_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int BLOCK, int CPT, int NQ, bool GROUPED, bool FUSED>
+__device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const int z, uint32_t *pack, SampleLds &sl, uint32_t *done_chunk)
+{
+    uint32_t &s_ndrive = sl.ndrive, &s_nstay = sl.nstay, &s_split = sl.split;
+    uint32_t(&gb)[kGroups] = sl.gb;
+    uint32_t(&stage)[kGroups * kStage] = sl.stage;
     const int Z = a.Z;
-    const int z = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
@@ -579,34 +711,41 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     // means the ids are in their registers.
     CPM_SSTAMP_DECL;
     CPM_SSTAMP(0);
-    const uint32_t n_raw = a.cnt[z];
+    const uint32_t ns_raw = a.cnt_s[z], na_raw = a.cnt_a[z];
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
+    // the bucket: stayers in slots [0, ns) of the region, arrivals in its last na slots; slot s of the workgroup reads position
+    // s + (s >= ns ? gap : 0), gap = cap - ns - na (clamped to the region: slots beyond ns + na hold no car)
+    const uint32_t ns = min(ns_raw, cap), na = min(na_raw, cap - ns);
+    const uint32_t n_all = ns + na;
+    const uint32_t ns4 = ns << 2, gap4 = (cap - n_all) << 2, top4 = (cap - 1) << 2;
     uint32_t id[CPT + 1];
 #pragma unroll
     for (int c = 0; c <= CPT; ++c) {
         // (the bucket's base in scalar registers + a 32-bit byte offset: cap x 4 B < 2^32)
-        const uint32_t off = min(static_cast<uint32_t>(tid + c * BLOCK), cap - 1) << 2;
+        const uint32_t s4 = static_cast<uint32_t>(tid + c * BLOCK) << 2;
+        const uint32_t off = min(s4 + (s4 >= ns4 ? gap4 : 0u), top4);
         asm volatile("global_load_dword %0, %1, %2" : "=v"(id[c]) : "v"(off), "s"(a.ids + b) : "memory");
     }
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     wait_ids<CPT + 1, NQ>(id);
     CPM_SSTAMP(1);
-    const uint32_t n_all = min(n_raw, cap);
     // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
     // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
     const bool heavy = n_all > kHeavy * CPT * BLOCK;
     if (tid == 0) {
         a.parking_t[z] = n_all;  // every car present at hour t, drivers included (src/saveresults.jl:12)
+        if (static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(a.rare->status, 2ull);  // the two ends of the bucket met: step invalid
         s_ndrive = 0;
         s_nstay = 0;
         uint32_t split = 0;
         if (heavy) {
-            atomicMax(&a.maxn[0], n_all);
-            const uint32_t idx = atomicAdd(a.nheavy_t, 1u);
-            atomicMax(&a.maxn[1], idx + 1u);
-            if (GROUPED && a.parts > 1 && idx < a.hgrid) {
-                a.heavy_list[idx] = static_cast<uint32_t>(z);
+            const GroupedRare *r = a.rare;
+            atomicMax(&r->maxn[0], n_all);
+            const uint32_t idx = atomicAdd(r->nheavy + a.hour, 1u);
+            atomicMax(&r->maxn[1], idx + 1u);
+            if (GROUPED && r->parts > 1 && idx < r->hgrid) {
+                r->heavy_list[idx] = static_cast<uint32_t>(z);
                 split = 1;
             }
         }
@@ -616,9 +755,10 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
     if (n_all == 0) {  // driving_t[z] stays 0 (zeroed by the caller)
         if (GROUPED) {
             if (tid == 0) a.cnt_next[z] = 0;
-            if (tid < kGroups) a.cntg[static_cast<size_t>(z) * kGroups + tid] = 0;
+            if (tid < kGroups) hand_store<FUSED>(&a.cntg[static_cast<size_t>(z) * kGroups + tid], 0u);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pack must not land in the LDS of the next workgroup
+        hand_off_done<FUSED>(done_chunk, tid);
         return;
     }
     // Philox of the register-resident cars: needs the ids only
@@ -657,7 +797,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo[c], khi[c]), last);
+                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
         }
     }
     CPM_SSTAMP(4);
@@ -688,7 +828,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
                 const uint32_t g = dest[c] >> a.gshift;
                 const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
                 if (rank[c] < static_cast<uint32_t>(kStage)) stage[g * kStage + rank[c]] = packed;
-                else if (rank[c] < a.scap) runs[g * a.scap + rank[c]] = packed;
+                else if (rank[c] < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank[c]], packed);
             }
         }
     } else {
@@ -702,7 +842,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         if (q0 + static_cast<uint32_t>(tid & ~63) >= n) continue;  // none of this wave's 64 slots holds a car (no barrier inside the loop)
         const uint32_t q = q0 + tid;
         const bool valid1 = q < n;
-        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q] : 0u);
+        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q + (q >= ns ? cap - n_all : 0u)] : 0u);
         const uint64_t car = a.cars.global(idx);
         long long kb;
         uint32_t clo1[1], khi1[1], dest1[1];
@@ -712,7 +852,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         want1[0] = drive1 & (last != 0.0);
         pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
         if (!want1[0]) dest1[0] = z;
-        else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo1[0], khi1[0]), last);
+        else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
         if (GROUPED) {
             const unsigned long long m1 = ballot64(valid1 & !drive1);
             uint32_t b1 = 0;
@@ -724,7 +864,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
                 const uint32_t rank = atomicAdd(&gb[g], 1u);
                 const uint32_t packed = idx | ((dest1[0] & ((1u << a.gshift) - 1u)) << a.idbits);
                 if (rank < static_cast<uint32_t>(kStage)) stage[g * kStage + rank] = packed;
-                else if (rank < a.scap) runs[g * a.scap + rank] = packed;
+                else if (rank < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank], packed);
             }
         } else {
             if (valid1) stay_out[q] = dest1[0] | (drive1 ? kDriveBit : 0u);
@@ -742,20 +882,32 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
         // staged drivers -> their runs: 16 lanes per group, 64 B per store
         for (int g = tid >> 4; g < kGroups; g += BLOCK / 16) {
             const uint32_t lim = min(gb[g], static_cast<uint32_t>(kStage));
-            for (uint32_t i = tid & 15; i < lim; i += 16) runs[g * a.scap + i] = stage[g * kStage + i];
+            for (uint32_t i = tid & 15; i < lim; i += 16) hand_store<FUSED>(&runs[g * a.scap + i], stage[g * kStage + i]);
         }
         if (tid < kGroups) {
             const uint32_t c = gb[tid];
-            a.cntg[static_cast<size_t>(z) * kGroups + tid] = min(c, a.scap);
-            if (c > a.scap) atomicOr(a.status, 2ull);  // a run outgrew its slot: the caller grows the regions and repeats
+            hand_store<FUSED>(&a.cntg[static_cast<size_t>(z) * kGroups + tid], min(c, a.scap));
+            if (c > a.scap) atomicOr(a.rare->status, 2ull);  // a run outgrew its slot: the caller grows the regions and repeats
         }
     }
     if (tid == 0) {
         a.driving_t[z] = GROUPED ? n - s_nstay : s_ndrive;  // every car of the bucket either stays or drives
-        if (GROUPED) a.cnt_next[z] = s_nstay;  // k_grouped_place adds the arrivals
+        if (GROUPED) {
+            a.cnt_next[z] = s_nstay;
+            if (s_nstay > cap) atomicOr(a.rare->status, 2ull);  // (cannot happen: stayers <= the bucket <= cap)
+        }
     }
     CPM_SSTAMP(7);
     CPM_SSTAMP_FLUSH;
+    hand_off_done<FUSED>(done_chunk, tid);
+}
+
+template <int BLOCK, int CPT, int NQ, bool GROUPED>
+__global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample(GroupedArgs a)
+{
+    extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
+    __shared__ SampleLds sl;
+    grouped_sample_body<BLOCK, CPT, NQ, GROUPED, false>(a, blockIdx.x, pack, sl, nullptr);
 }
 
 // The rest of the HEAVY buckets (real Uber Movement tables are peaky: a central zone can hold tens of times the mean, and one
@@ -763,8 +915,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
 // k_grouped_sample when the context has seen such buckets (GroupedArgs::parts > 1), with parts - 1 blocks for each of the hgrid
 // zones the sampler may list in heavy_list: block (i, q) takes the chunks q, q + (parts - 1), ... of CPT * BLOCK cars behind the first
 // one of the i-th listed zone.  It shares the zone's outputs with the first workgroup and its sibling blocks, which have already written theirs
-// or are writing them now: stayers take their slots in next hour's bucket with one global ticket per wave (cnt_next[z], which the
-// placing kernel goes on adding to), drivers are ranked per chunk in LDS and reserve their range of the zone's runs with one
+// or are writing them now: stayers take their slots in next hour's bucket with one global ticket per wave (cnt_next[z]), drivers are ranked per chunk in LDS and reserve their range of the zone's runs with one
 // global atomic per (chunk, destination group) on the run length, driving counts are added.  Order inside buckets and runs is
 // arbitrary anyway (a car's draws depend on its id only, counts are order-free).
 template <int BLOCK, int CPT, int NQ>
@@ -773,13 +924,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     extern __shared__ uint32_t pack[];
     __shared__ uint32_t gb[kGroups], gbase[kGroups];
     const int Z = a.Z;
-    if (blockIdx.x >= min(*a.nheavy_t, a.hgrid)) return;  // (the list of this hour is shorter than the grid)
-    const int z = static_cast<int>(a.heavy_list[blockIdx.x]);
-    const uint32_t q = blockIdx.y, nq = a.parts - 1u;
+    const GroupedRare *rare = a.rare;
+    if (blockIdx.x >= min(rare->nheavy[a.hour], rare->hgrid)) return;  // (the list of this hour is shorter than the grid)
+    const int z = static_cast<int>(rare->heavy_list[blockIdx.x]);
+    const uint32_t q = blockIdx.y, nq = rare->parts - 1u;
+    unsigned long long *status = rare->status;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr uint32_t L = CPT * BLOCK;
     const uint32_t cap = a.cap;
-    const uint32_t n = min(a.cnt[z], cap);
+    const uint32_t ns = min(a.cnt_s[z], cap), na = min(a.cnt_a[z], cap - ns);
+    const uint32_t n = ns + na, gap = cap - n;
     const uint32_t start0 = L * (1u + q);
     if (start0 >= n) return;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
@@ -804,7 +958,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         for (int c = 0; c < CPT; ++c) {
             const uint32_t s = start + static_cast<uint32_t>(tid + c * BLOCK);
             valid[c] = s < n;
-            id[c] = a.ids[b + min(s, n - 1u)];
+            const uint32_t sc = min(s, n - 1u);
+            id[c] = a.ids[b + sc + (sc >= ns ? gap : 0u)];
         }
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
@@ -823,7 +978,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         if (__builtin_expect(any64(anyx), 0)) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.ckpt_t, a.p_t, a.nf_t, Z, z, u53(clo[c], khi[c]), last);
+                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
         }
         // stayers: one global ticket per wave
         unsigned long long mS[CPT];
@@ -836,7 +991,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         uint32_t bS = 0;
         if (lane == 0 && total) {
             bS = atomicAdd(&a.cnt_next[z], total);
-            if (bS + total > cap) atomicOr(a.status, 2ull);
+            if (bS + total > cap) atomicOr(status, 2ull);
         }
         bS = from_lane0(bS);
         uint32_t rank[CPT];
@@ -857,7 +1012,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             uint32_t base = 0;
             if (c) {
                 base = atomicAdd(&a.cntg[static_cast<size_t>(z) * kGroups + tid], c);
-                if (base + c > a.scap) atomicOr(a.status, 2ull);
+                if (base + c > a.scap) atomicOr(status, 2ull);
             }
             gbase[tid] = base;
             gb[tid] = 0;
@@ -877,6 +1032,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     if (lane == 0 && nd) atomicAdd(&a.driving_t[z], static_cast<unsigned long long>(nd));
 }
 
+
 // ------------------------------------------------------------------------------------------------ placing the drivers
 // Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share blockIdx % 8 (one XCD,
 // one L2: all writes to a bucket merge there; speed only, never correctness).  Block (g, j) takes the group-g runs of the origin
@@ -891,28 +1047,40 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
 // So the block's entries are first sorted by destination zone in LDS (their rank inside the block is known from pass A, the
 // zones' offsets from a scan of the block's histogram) and then written out in that order: consecutive lanes write consecutive
 // slots of one bucket.
-template <int PB, int KRUNS, int KDEEP>
-__global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
-                                                               int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
-                                                               uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ ids_next,
-                                                               unsigned long long *status)
+// LDS of a placing block beside its sorted list (one object: the fused kernel overlays it with the sampler workgroups')
+// bins : per destination zone: entries held in registers (pass A), then their first index in the sorted list
+// tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those inside the bucket
+// delta: (this block's first position inside the zone's bucket) - (the zone's first index in the sorted list)
+// lstart: runs longer than the 16 * KDEEP entries their lanes hold (skewed tables: a heavy origin zone, a popular destination group):
+//         the entries beyond are dealt over ALL threads of the block -- lstart[r] = first index of run r's surplus in that flat list
+template <int PB, int KRUNS, int ZPG>
+struct PlaceLds {
+    uint32_t bins[ZPG], tbins[ZPG], delta[ZPG];
+    uint32_t wsum[PB / 64], total;
+    uint32_t lstart[KRUNS * (PB / 16) + 1], any_long, go;
+};
+
+// FUSED: the block's input is written by sampler workgroups of the SAME launch (those of chunk j of origin zones: lower block
+// indices, dispatched before it).  One wave polls the chunk's counter (relaxed agent-scope loads, s_sleep between them) until all
+// `need` workgroups have counted themselves in; the wait is bounded: when it runs out the block raises bit 2 of the status word and
+// leaves -- the step is then invalid and the context repeats it with two launches per hour (a placement or dispatch order this
+// protocol did not expect can cost time, never a hang).  The runs are then read with sc1 loads (hand_load).
+constexpr uint32_t kFusedSpinLimit = 1u << 15;  // default number of polls: x (one L2 round trip + s_sleep 32) = tens of milliseconds
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+__device__ __forceinline__ void grouped_place_body(const int g, const int j, PlaceLds<PB, KRUNS, ZPG> &pl, uint32_t *sorted_ids, const uint32_t *__restrict__ D,
+                                                   const uint32_t *__restrict__ cntg, int zpg, int zps, int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
+                                                   uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next, unsigned long long *status,
+                                                   const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit)
 {
     constexpr int kPlaceBlock = PB, kPlaceSeg = PB / 16;
     constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;  // entries a block can hold in registers
-    // bins : per destination zone: entries held in registers (pass A), then their first index in the sorted list
-    // tbins: entries beyond 16 * KDEEP of their run (re-read in pass B), then the running position of those inside the bucket
-    // delta: (this block's first position inside the zone's bucket) - (the zone's first index in the sorted list)
-    __shared__ uint32_t bins[kMaxZonesPerGroup], tbins[kMaxZonesPerGroup], delta[kMaxZonesPerGroup];
-    __shared__ uint32_t wsum[kPlaceBlock / 64], s_total;
-    // runs longer than the 16 * KDEEP entries their lanes hold (skewed tables: a heavy origin zone, a popular destination group): the
-    // entries beyond are dealt over ALL threads of the block -- lstart[r] = first index of run r's surplus in that flat list
     constexpr int kRuns = KRUNS * kPlaceSeg;
     constexpr int kSurplusBatch = 4;
-    __shared__ uint32_t lstart[kRuns + 1], s_any_long;
-    extern __shared__ uint32_t sorted_ids[];                                  // [kSlots] ids in destination order
+    uint32_t(&bins)[ZPG] = pl.bins, (&tbins)[ZPG] = pl.tbins, (&delta)[ZPG] = pl.delta;
+    uint32_t(&wsum)[PB / 64] = pl.wsum, &s_total = pl.total;
+    uint32_t(&lstart)[kRuns + 1] = pl.lstart, &s_any_long = pl.any_long;
     uint16_t *sorted_zone = reinterpret_cast<uint16_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x % kGroups, j = blockIdx.x / kGroups;
     const int zg0 = g * zpg;
     const int nzl = max(0, min(zpg, Z - zg0));
     const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
@@ -926,14 +1094,33 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
     }
     if (tid == 0) s_any_long = 0;
     if (zs0 >= zs1) return;  // (uniform per block)
+    if constexpr (FUSED) {
+        if (wave == 0) {
+            bool ok = false;
+            for (uint32_t spins = 0; spins < spin_limit; ++spins) {
+                const uint32_t seen = from_lane0(lane == 0 ? __hip_atomic_load(done_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+                if (seen >= need) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);  // (~1 us between polls)
+            }
+            if (tid == 0) pl.go = ok ? 1u : 0u;
+        }
+        lds_barrier();  // (the polling wave's loads come after its poll matched, the other waves' after this barrier)
+        if (pl.go == 0u) {
+            if (tid == 0) atomicOr(status, 4ull);
+            return;
+        }
+    }
     uint32_t c[KRUNS], v[KRUNS][KDEEP], r[KRUNS][KDEEP];
 #pragma unroll
     for (int k = 0; k < KRUNS; ++k) {  // (nothing here depends on a loaded value: all 12 requests leave before the first wait)
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
-        c[k] = cntg[run];
+        c[k] = hand_load<FUSED>(&cntg[run]);
 #pragma unroll
-        for (int d = 0; d < KDEEP; ++d) v[k][d] = D[run * scap + l16 + 16 * d];  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
+        for (int d = 0; d < KDEEP; ++d) v[k][d] = hand_load<FUSED>(&D[run * scap + l16 + 16 * d]);  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
     }
     lds_barrier();
     CPM_PSTAMP(1);
@@ -969,7 +1156,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
         for (int step = kRuns / 2; step > 0; step >>= 1)
             if (lstart[r + step] <= e) r += step;
         const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + (r % kPlaceSeg) + (r / kPlaceSeg) * kPlaceSeg = zs0 + r)
-        return D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - lstart[r])];
+        return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - lstart[r])]);
     };
     const bool any_long = s_any_long != 0;  // (block-uniform)
     uint32_t ltotal = 0;
@@ -1004,7 +1191,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
     const bool zone = tid < nzl;
     const uint32_t cr = zone ? bins[tid] : 0u, ct = zone ? tbins[tid] : 0u;
     uint32_t base = 0;
-    if (cr + ct) base = atomicAdd(&cnt_next[zg0 + tid], cr + ct);
+    if (cr + ct) base = atomicAdd(&cnt_a_next[zg0 + tid], cr + ct);
     uint32_t first;
     {
         uint32_t incl = cr;
@@ -1047,7 +1234,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
     for (uint32_t i = tid; i < total; i += kPlaceBlock) {
         const uint32_t dl = sorted_zone[i];
         const uint32_t p = delta[dl] + i;
-        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = sorted_ids[i];
+        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = sorted_ids[i];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
     for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {
@@ -1059,7 +1246,7 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
             if (e0 + u * kPlaceBlock < ltotal) {
                 const uint32_t dl = w[u] >> idbits;
                 const uint32_t p = atomicAdd(&tbins[dl], 1u);
-                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + p] = w[u] & idmask;
+                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
             }
     }
     CPM_PSTAMP(7);
@@ -1067,6 +1254,62 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
 #endif
     CPM_PSTAMP_FLUSH;
+}
+
+template <int PB, int KRUNS, int KDEEP>
+__global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int zpg, int zps,
+                                                               int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
+                                                               uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next,
+                                                               unsigned long long *status)
+{
+    __shared__ PlaceLds<PB, KRUNS, kMaxZonesPerGroup> pl;
+    extern __shared__ uint32_t sorted_ids[];  // [kSlots] ids in destination order, then [kSlots] u16: their zone inside the group
+    grouped_place_body<PB, KRUNS, KDEEP, kMaxZonesPerGroup, false>(blockIdx.x % kGroups, blockIdx.x / kGroups, pl, sorted_ids, D, cntg, zpg, zps, Z, cap,
+                                                                    scap, idbits, cnt_a_next, ids_next, status, nullptr, 0u, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------ the fused hour
+// ONE launch per hour: the sampler workgroups of hour t AND the placing blocks that move hour t's drivers into hour t + 1's
+// buckets.  A placing block (destination group g, chunk j of kFusedChunk origin zones) needs the runs of exactly the kFusedChunk
+// sampler workgroups of its chunk -- not the whole launch -- so it can run while later zones are still being sampled: the placing
+// kernel is a chain of memory round trips that leaves the vector units idle, the sampler is bound by what it issues, and side by
+// side they fill each other's gaps (two INDEPENDENT resamples on two streams gain 24 % that way, profiles/round2_notes.md; this
+// is the same overlap inside one resample).  Block order: chunk c = kFusedChunk sampler workgroups, then the kGroups placing
+// blocks of chunk c - lag; a block only ever waits for blocks of LOWER index, which the dispatcher has started before it, so the
+// wait cannot deadlock however the blocks are placed; it is bounded all the same (grouped_place_body).  Chunk size + kGroups is a
+// multiple of 8: the placing blocks of one group share blockIdx % 8 = one XCD = one L2, as in the two-launch form (speed only).
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): runs and run lengths stored sc1 by the samplers, every storing wave
+// drains (s_waitcnt vmcnt(0)), workgroup barrier, one agent-scope add on the chunk's counter; the placing block polls that counter
+// with relaxed agent-scope loads and reads the runs with sc1 loads.  Everything else crosses a kernel boundary as before: the
+// buckets the placing blocks fill are read by the NEXT launch.
+constexpr int kFusedChunk = 64;  // origin zones per chunk = runs a 256-thread placing block takes (16 lanes per run, KRUNS = 4)
+constexpr int kDoneStride = 32;  // words between the hand-off counters of consecutive chunks: a 128-B line each (64 adds and the polls of 32
+                                 // placing blocks per counter; with all of an hour's counters in two lines every add and every poll of the
+                                 // launch queued at one memory channel: 300 us per launch instead of 30)
+constexpr int kFusedZpg = 256;   // zones per destination group the fused form is built for (Z <= 8,192)
+
+template <int CPT, int NQ>
+__global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_hour(GroupedArgs a)
+{
+    extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
+    __shared__ union {
+        SampleLds s;
+        PlaceLds<kFusedThreads, 4, kFusedZpg> p;
+    } u;
+    constexpr int per = kFusedChunk + kGroups;
+    const int c = blockIdx.x / per, q = blockIdx.x % per;
+    const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
+    if (q < kFusedChunk) {
+        const int z = c * kFusedChunk + q;
+        if (c >= nchunk || z >= a.Z) return;
+        grouped_sample_body<kFusedThreads, CPT, NQ, true, true>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(c) * kDoneStride);
+    } else {
+        const int j = c - a.lag;
+        if (j < 0) return;
+        const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
+        grouped_place_body<kFusedThreads, 4, 2, kFusedZpg, true>(q - kFusedChunk, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap,
+                                                                  a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit);
+    }
 }
 
 // Geometry of a placing launch: threads per block, runs per 16-lane group (KRUNS = 4 or 8), blocks per destination group
@@ -1296,8 +1539,59 @@ inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
     else grouped_launch_nq<GROUPED, CPT, 40>(a, lds, stream);
 }
 
+inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2 : 4); }
+
+// the fused hour (k_grouped_hour): (chunks + lag) x (kFusedChunk sampler workgroups + kGroups placing blocks)
+inline size_t fused_lds_bytes(int Zq, int G)
+{
+    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(6) * 4 * 2 * kFusedThreads);
+}
 template <int CPT, int NQ>
-inline void grouped_launch_heavy_nq(const GroupedArgs &a, size_t lds, hipStream_t stream)
+inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
+{
+    const size_t lds = fused_lds_bytes(a.Zq, a.G);
+    if (lds > 48 * 1024) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour<CPT, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
+    launch(k_grouped_hour<CPT, NQ>, dim3(static_cast<unsigned>((nchunk + a.lag) * (kFusedChunk + kGroups))), dim3(kFusedThreads), lds, stream, a);
+}
+// true when an instantiation exists for this problem (the common pack sizes; others take two launches per hour)
+inline bool fused_shape_ok(int Z, int Zq, int G)
+{
+    const int need = (pack_row_words(Zq, G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    return (1 << grouped_gshift_of(Z)) <= kFusedZpg && need <= 12;
+}
+template <int CPT>
+inline void grouped_launch_hour_c(const GroupedArgs &a, hipStream_t stream)
+{
+    const int need = (pack_row_words(a.Zq, a.G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (need <= 1) grouped_launch_hour_nq<CPT, 1>(a, stream);
+    else if (need <= 2) grouped_launch_hour_nq<CPT, 2>(a, stream);
+    else if (need <= 3) grouped_launch_hour_nq<CPT, 3>(a, stream);
+    else if (need <= 4) grouped_launch_hour_nq<CPT, 4>(a, stream);
+    else if (need <= 5) grouped_launch_hour_nq<CPT, 5>(a, stream);
+    else if (need <= 6) grouped_launch_hour_nq<CPT, 6>(a, stream);
+    else if (need <= 8) grouped_launch_hour_nq<CPT, 8>(a, stream);
+    else grouped_launch_hour_nq<CPT, 12>(a, stream);
+}
+inline void grouped_launch_hour(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+{
+    switch (grouped_cpt(mean)) {
+    case 1: grouped_launch_hour_c<1>(a, stream); break;
+    case 2: grouped_launch_hour_c<2>(a, stream); break;
+    default: grouped_launch_hour_c<4>(a, stream); break;
+    }
+}
+
+template <int CPT, int NQ>
+inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, size_t lds, hipStream_t stream)
 {
     if (lds > 48 * 1024) {
         static bool attr_done[64] = {};
@@ -1309,30 +1603,29 @@ inline void grouped_launch_heavy_nq(const GroupedArgs &a, size_t lds, hipStream_
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(a.hgrid, a.parts - 1), dim3(kSampleBlock), lds, stream, a);
+    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(hgrid, parts - 1), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <int CPT>
-inline void grouped_launch_heavy_c(const GroupedArgs &a, hipStream_t stream)
+inline void grouped_launch_heavy_c(const GroupedArgs &a, int parts, int hgrid, hipStream_t stream)
 {
     const int words = pack_row_words(a.Zq, a.G);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
-    if (need <= 2) grouped_launch_heavy_nq<CPT, 2>(a, lds, stream);
-    else if (need <= 5) grouped_launch_heavy_nq<CPT, 5>(a, lds, stream);
-    else if (need <= 12) grouped_launch_heavy_nq<CPT, 12>(a, lds, stream);
-    else grouped_launch_heavy_nq<CPT, 40>(a, lds, stream);
+    if (need <= 2) grouped_launch_heavy_nq<CPT, 2>(a, parts, hgrid, lds, stream);
+    else if (need <= 5) grouped_launch_heavy_nq<CPT, 5>(a, parts, hgrid, lds, stream);
+    else if (need <= 12) grouped_launch_heavy_nq<CPT, 12>(a, parts, hgrid, lds, stream);
+    else grouped_launch_heavy_nq<CPT, 40>(a, parts, hgrid, lds, stream);
 }
 
-inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2 : 4); }
 
-inline void grouped_launch_heavy(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+inline void grouped_launch_heavy(const GroupedArgs &a, int parts, int hgrid, int64_t mean, hipStream_t stream)
 {
-    if (a.parts <= 1 || a.hgrid == 0) return;
+    if (parts <= 1 || hgrid == 0) return;
     switch (grouped_cpt(mean)) {
-    case 1: grouped_launch_heavy_c<1>(a, stream); break;
-    case 2: grouped_launch_heavy_c<2>(a, stream); break;
-    default: grouped_launch_heavy_c<4>(a, stream); break;
+    case 1: grouped_launch_heavy_c<1>(a, parts, hgrid, stream); break;
+    case 2: grouped_launch_heavy_c<2>(a, parts, hgrid, stream); break;
+    default: grouped_launch_heavy_c<4>(a, parts, hgrid, stream); break;
     }
 }
 
@@ -1351,8 +1644,8 @@ inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
 // installed row, through the same staging, search and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
 __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__restrict__ pack_g, const double *__restrict__ last_p,
-                                                           const double *__restrict__ ckpt_t, const double *__restrict__ p_t,
-                                                           const double *__restrict__ nf_t, int origin, int Z, int Zq, int G, int64_t n,
+                                                           const double *__restrict__ ckpt_t, const double *__restrict__ p_t, int origin, int Z, int Zq,
+                                                           int G, int64_t n,
                                                            const uint64_t *__restrict__ k53, int64_t *__restrict__ out, int *__restrict__ n_exact)
 {
     extern __shared__ uint32_t pack[];
@@ -1388,7 +1681,7 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
             continue;
         }
         if (!ok[0]) {
-            dest[0] = search_exact_ckpt(ckpt_t, p_t, nf_t, Z, origin, static_cast<double>(k) * 0x1.0p-53, last);
+            dest[0] = search_exact_tables(ckpt_t, p_t, Z, origin, static_cast<double>(k) * 0x1.0p-53, last, khi[0] <= hi_last ? static_cast<int>(dest[0]) : -1);
             atomicAdd(n_exact, 1);
         }
         out[i] = static_cast<int64_t>(dest[0]) + 1;
@@ -1428,11 +1721,15 @@ struct GroupedWork {
     int cap_mult_alloc = 0;  // what the arrays below were sized for
     uint32_t cap = 0, scap = 0, idbits = 0, gshift = 0;
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [Z*cap]: cached initial bucketing, ping-pong
-    uint32_t *cnt0 = nullptr;                                    // [Z] sizes of the cached initial buckets
-    uint32_t *cnt = nullptr;                                     // [T+1][Z] bucket sizes per hour
+    uint32_t *cnt0 = nullptr;                                    // [2][Z] the cached initial buckets: stayers (all cars after bucketing) | arrivals
+    uint32_t *cnt = nullptr;                                     // [T+1][2][Z] per hour: stayers | arrivals of every bucket; then [T][chunks] the fused hour's hand-off counters
+    bool fused_ok = true;                                        // the fused hour is used (CPM_OPT_FUSED; cleared for good when a placing block gave up waiting)
+    int fused_lag = 2;                                           // chunks of sampler workgroups between a chunk and its placing blocks
+    uint32_t fused_spin = kFusedSpinLimit;
     uint32_t *Dq = nullptr;                                      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;                                    // [Z][kGroups] run lengths
     unsigned long long *tt_part = nullptr;                       // [kTravelParts] partial travel-time sums, kept zero between resamples
+    GroupedRare *rare = nullptr;                                 // what the rare branches of the hourly kernels read (written by k_grouped_zero per run)
     uint32_t *maxn = nullptr;                                    // [2] of the current run: largest heavy bucket (> kHeavy x the sampler workgroup's slots), most heavy buckets in one hour
     uint32_t *heavy_list = nullptr, *nheavy = nullptr;           // [kHeavyCap] zones handed to the heavy kernel this hour; [T+1] how many, per hour
     int run_hours = 1;                                           // copies of Dq / cntg: 1, or T when the runs of every hour of a resample are kept (ensure_history)
@@ -1448,6 +1745,9 @@ struct GroupedWork {
         hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 8)) : 0;
     }
 
+    size_t fused_chunks() const { return static_cast<size_t>((Z + kFusedChunk - 1) / kFusedChunk); }
+    size_t done_base() const { return (static_cast<size_t>(T + 1) * 2 * Z + kDoneStride - 1) / kDoneStride * kDoneStride; }  // (whole lines)
+    size_t cnt_words() const { return done_base() + static_cast<size_t>(T) * fused_chunks() * kDoneStride; }
     size_t run_words() const { return static_cast<size_t>(Z) * kGroups * scap; }
     size_t len_words() const { return static_cast<size_t>(Z) * kGroups; }
     // Room for the runs of all T hours (travel times in one launch at the end of a resample), when they fit 24 GiB; else one copy.
@@ -1479,6 +1779,8 @@ struct GroupedWork {
         tt_part = nullptr;
         if (maxn) (void)hipFree(maxn);
         maxn = nullptr;
+        if (rare) (void)hipFree(rare);
+        rare = nullptr;
         n = 0;
         run_hours = 1;
         buckets0_valid = false;
@@ -1506,8 +1808,8 @@ struct GroupedWork {
         alloc(&ids0, slots);
         alloc(&idsA, slots);
         alloc(&idsB, slots);
-        alloc(&cnt0, Z);
-        alloc(&cnt, static_cast<size_t>(T + 1) * Z);
+        alloc(&cnt0, 2 * static_cast<size_t>(Z));
+        alloc(&cnt, cnt_words());
         alloc(&Dq, static_cast<size_t>(Z) * kGroups * scap);
         alloc(&cntg, static_cast<size_t>(Z) * kGroups);
         alloc(&heavy_list, kHeavyCap);
@@ -1515,6 +1817,7 @@ struct GroupedWork {
         if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMalloc(&maxn, 2 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&rare, sizeof(GroupedRare));
         if (e != hipSuccess) release();
         return e;
     }
@@ -1526,21 +1829,23 @@ struct GroupedTables {
     const long long *thr;    // [T][Z]
     const double *ckpt;      // [T][nck][Z] checkpoints of the running sums
     const double *p;         // [T][Z dest][Z origin] p_destin (reference layout)
-    const double *nf;        // [T][Z] row normalisers or null
     const double2 *tt;       // [T][Z][Z] travel table (k_build_travel_table) or nullptr
     int Z, Zp, Zq, T;
 };
 
 // Everything a run starts from zero, in ONE launch: the count tensor (driving counts, time sum and status word are added to),
-// the largest-bucket words and the per-hour heavy counts.  (Five hipMemsetAsync calls were five ~5 us fill kernels in the stream of
-// every resample, 2.5 % of it; the bucket sizes of the hours need no zeroing at all: the sampler stores every zone's stayers.)
+// the largest-bucket words, the per-hour heavy counts and the per-hour bucket counts (the arrivals are added to; the stayers are
+// stored by the sampler).  (Five hipMemsetAsync calls were five ~5 us fill kernels in the stream of every resample, 2.5 % of it.)
 __global__ __launch_bounds__(256) void k_grouped_zero(unsigned long long *__restrict__ counts, size_t nwords, uint32_t *__restrict__ maxn,
-                                                      uint32_t *__restrict__ nheavy, int nh)
+                                                      uint32_t *__restrict__ nheavy, int nh, uint32_t *__restrict__ cnt, size_t ncnt,
+                                                      GroupedRare *__restrict__ rare, GroupedRare rare_now)
 {
     const size_t stride = static_cast<size_t>(gridDim.x) * 256;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < nwords; i += stride) counts[i] = 0ull;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < ncnt; i += stride) cnt[i] = 0u;  // (the arrival counts are added to)
     if (blockIdx.x == 0) {
         if (threadIdx.x < 2) maxn[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) *rare = rare_now;  // (what the rare branches of this run's kernels read)
         for (int k = threadIdx.x; k < nh; k += 256) nheavy[k] = 0u;
     }
 }
@@ -1577,12 +1882,22 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     {
         const size_t nwords = 2 * static_cast<size_t>(T) * Z + 2;
         const unsigned zgrid = static_cast<unsigned>(std::min<size_t>((nwords + 255) / 256, 1024));
-        hipLaunchKernelGGL(k_grouped_zero, dim3(zgrid), dim3(256), 0, stream, parking, nwords, w.maxn, w.nheavy, T + 1);
+        GroupedRare rn{};
+        rn.ckpt = tb.ckpt;
+        rn.p = tb.p;
+        rn.maxn = w.maxn;
+        rn.heavy_list = w.heavy_list;
+        rn.nheavy = w.nheavy;
+        rn.status = status;
+        rn.hgrid = static_cast<uint32_t>(w.hgrid);
+        rn.parts = static_cast<uint32_t>(w.parts);
+        rn.Z = Z;
+        hipLaunchKernelGGL(k_grouped_zero, dim3(zgrid), dim3(256), 0, stream, parking, nwords, w.maxn, w.nheavy, T + 1, w.cnt, w.cnt_words(), w.rare, rn);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zeroing the counters");
     }
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
         const int64_t chunk = (n + w.nb0 - 1) / w.nb0;
-        if ((e = hipMemsetAsync(w.cnt0, 0, sizeof(uint32_t) * Z, stream)) != hipSuccess) return hip_fail(e, "memset cnt0");
+        if ((e = hipMemsetAsync(w.cnt0, 0, sizeof(uint32_t) * 2 * Z, stream)) != hipSuccess) return hip_fail(e, "memset cnt0");
         hipLaunchKernelGGL(k_bucket_cars, dim3(w.nb0), dim3(kBucketBlock), lds_bins, stream, d_zone0, n, chunk, Z, w.cap, w.cnt0, w.ids0, status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
         w.buckets0_valid = true;
@@ -1600,31 +1915,24 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         // which are computed from the runs
         const bool last_hour = !ivp && t + 1 == T;
         const bool grouped = !last_hour || travel;
-        uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * Z;
+        uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * 2 * Z;  // stayers; the arrivals Z words behind
         uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
         GroupedArgs a;
         a.ids = ids;
-        a.cnt = cnt;
+        a.cnt_s = cnt;
+        a.cnt_a = cnt + Z;
         a.rp_t = tb.rp + static_cast<size_t>(t) * Z * rw;
         a.last_t = tb.last + static_cast<size_t>(t) * Z;
         a.thr_t = tb.thr + static_cast<size_t>(t) * Z;
-        a.ckpt_t = tb.ckpt + static_cast<size_t>(t) * ckpt_count(Z) * Z;
-        a.p_t = tb.p + static_cast<size_t>(t) * Z * Z;
-        a.nf_t = tb.nf ? tb.nf + static_cast<size_t>(t) * Z : nullptr;
+        a.rare = w.rare;
+        a.hour = t;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
         a.D = w.Dq + (history ? w.run_words() * t : 0);
         a.cntg = w.cntg + (history ? w.len_words() * t : 0);
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
-        a.status = status;
-        a.maxn = w.maxn;
-        a.heavy_list = w.heavy_list;
-        a.nheavy_t = w.nheavy + t;
-        a.parts = grouped ? static_cast<uint32_t>(w.parts) : 1u;
-        a.hgrid = grouped ? static_cast<uint32_t>(w.hgrid) : 0u;
         a.Z = Z;
-        a.Zp = tb.Zp;
         a.Zq = tb.Zq;
         a.G = G;
         a.cap = w.cap;
@@ -1634,15 +1942,23 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.step = step;
         a.cars = cars;
         a.seed = seed;
+        // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
+        const bool fuse = grouped && !last_hour && w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G);
+        a.done_t = w.cnt + w.done_base() + static_cast<size_t>(t) * w.fused_chunks() * kDoneStride;
+        a.lag = w.fused_lag;
+        a.spin_limit = w.fused_spin;
         prof_begin(CPM_PROFILE_SAMPLER);
-        if (grouped) grouped_launch_sample<true>(a, mean, stream);
+        if (fuse) grouped_launch_hour(a, mean, stream);
+        else if (grouped) grouped_launch_sample<true>(a, mean, stream);
         else grouped_launch_sample<false>(a, mean, stream);
         prof_end(CPM_PROFILE_SAMPLER);
-        if (grouped) grouped_launch_heavy(a, mean, stream);
+        if (grouped && !fuse) grouped_launch_heavy(a, w.parts, w.hgrid, mean, stream);
         if (!last_hour) {
-            prof_begin(CPM_PROFILE_PLACE);
-            grouped_launch_place(stream, a.D, a.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next, ids_next, status);
-            prof_end(CPM_PROFILE_PLACE);
+            if (!fuse) {
+                prof_begin(CPM_PROFILE_PLACE);
+                grouped_launch_place(stream, a.D, a.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next + Z, ids_next, status);
+                prof_end(CPM_PROFILE_PLACE);
+            }
             ids = ids_next;
             cnt = cnt_next;
         }
@@ -1682,7 +1998,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "travel-time sum");
     }
     if (ivp) {
-        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, w.cap, d_zone0_out);
+        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, cnt + Z, w.cap, d_zone0_out, status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
         w.ivp_ids = ids;
         w.ivp_cnt = cnt;
@@ -1696,7 +2012,7 @@ inline hipError_t grouped_commit_ivp(GroupedWork &w, hipStream_t stream)
 {
     hipError_t e = hipSuccess;
     if (w.ivp_ids != w.ids0) e = hipMemcpyAsync(w.ids0, w.ivp_ids, sizeof(uint32_t) * static_cast<size_t>(w.Z) * w.cap, hipMemcpyDeviceToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(w.cnt0, w.ivp_cnt, sizeof(uint32_t) * w.Z, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess && w.ivp_cnt != w.cnt0) e = hipMemcpyAsync(w.cnt0, w.ivp_cnt, sizeof(uint32_t) * 2 * w.Z, hipMemcpyDeviceToDevice, stream);
     if (e == hipSuccess) w.buckets0_valid = true;
     return e;
 }

@@ -157,39 +157,37 @@ __global__ __launch_bounds__(256) void k_pdest_weights(const double *__restrict_
     }
 }
 
-// nf[i,t] = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33).  The division by it
-// (:38-46) is NOT a pass of its own: k_build_rows and search_exact_ckpt divide an entry where they read it (p / nf where nf > 0) --
-// the table stays as createpdestin's weights and is read once for the sums and once for everything the samplers use.
+// normalise per (i,t): nf = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33); divide if nf > 0
+// (:38-46).  One lane per origin: a first sweep for the sum (32 loads in flight per lane, added in order), a second one that divides.
+// (Dividing where the row tables are built instead -- inside the ONE lane per origin that forms the running sums -- was measured at
+// 1.58 ms against 0.64 + this kernel's second sweep at Z = 2,357: thirteen f64 instructions per entry in front of every addition.)
 constexpr int kSumBatch = 32;
-__global__ __launch_bounds__(64) void k_pdest_rowsum(const double *__restrict__ p, double *__restrict__ nf, int Z)
+__global__ __launch_bounds__(64) void k_pdest_normalise(double *__restrict__ p, int Z)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
     if (i >= Z) return;
-    const double *row = p + static_cast<size_t>(t) * Z * Z + i;
-    double s = 0.0;
+    double *row = p + static_cast<size_t>(t) * Z * Z + i;
+    double nf = 0.0;
     int j = 0;
     for (; j + kSumBatch <= Z; j += kSumBatch) {  // loads in batches, sum in order (see k_pdrive_mean)
         double v[kSumBatch];
 #pragma unroll
         for (int u = 0; u < kSumBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
 #pragma unroll
-        for (int u = 0; u < kSumBatch; ++u) s = s + v[u];
+        for (int u = 0; u < kSumBatch; ++u) nf = nf + v[u];
     }
-    for (; j < Z; ++j) s = s + row[static_cast<size_t>(j) * Z];
-    nf[i + static_cast<size_t>(t) * Z] = s;
-}
-
-// p[i,j,t] /= nf[i,t] where nf > 0 (createpdestin.jl:38-46) in place: only when the caller wants createpdestin's array on the host
-__global__ __launch_bounds__(256) void k_pdest_divide(double *__restrict__ p, const double *__restrict__ nf, int Z)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y, t = blockIdx.z;
-    if (i >= Z) return;
-    const double n = nf[i + static_cast<size_t>(t) * Z];
-    if (n > 0) {
-        double *q = p + i + static_cast<size_t>(Z) * (j + static_cast<size_t>(Z) * t);
-        *q = *q / n;
+    for (; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
+    if (nf > 0) {
+        j = 0;
+        for (; j + kSumBatch <= Z; j += kSumBatch) {
+            double v[kSumBatch];
+#pragma unroll
+            for (int u = 0; u < kSumBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
+#pragma unroll
+            for (int u = 0; u < kSumBatch; ++u) row[static_cast<size_t>(j + u) * Z] = v[u] / nf;
+        }
+        for (; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
     }
 }
 

@@ -61,6 +61,13 @@ class Sampler:
     def set_kernel(self, kernel):
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
 
+    def set_fused(self, mode=1, lag=None):
+        """The grouped path's fused hour: 1 on (default), 0 two launches per hour, 2 on with placing blocks that give up at once
+        (tests); lag: chunks of sampler workgroups in front of a chunk's placing blocks."""
+        _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED, int(mode)))
+        if lag is not None:
+            _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED_LAG, int(lag)))
+
     def get_info(self, what):
         """cpm_get_info: 1 = kernel family AUTO resolves to now, 2 = bucket-region size in multiples of the mean bucket."""
         v = C.c_int64(0)

@@ -444,6 +444,32 @@ def test_rccl_allreduce_on_the_sampler_stream(cpm):
     assert (out["sync"]["parking"], out["sync"]["driving"]) == want[SIM_SEED]
 
 
+@pytest.mark.parametrize("Z,cpz,T", [(700, 300, 24), (130, 1100, 6), (2357, 150, 4)])
+def test_fused_hour_equals_two_launches_per_hour(cpm, O, Z, cpz, T):
+    """The grouped path's hour as ONE launch (sampler workgroups + the placing blocks of their drivers, handed over inside the
+    launch) against two launches per hour and against the oracle: counts, post-IVP state, travel-time sum.  Also the bail-out:
+    with placing blocks that give up waiting at once every fused step comes back flagged, the blocking calls repeat it with two
+    launches, and the context stays there."""
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.3)
+    with cpm.Sampler(Z, T) as s:
+        s.set_datamatrix(dm, dist)
+        p_drive = s.build_p_drive(0.1, 0.9, 0.5)
+        p_dest = s.build_p_dest(2)
+        ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+        s.set_kernel(5)
+        for mode, lag in [(1, 1), (0, None), (1, 2), (1, 7), (2, None)]:
+            s.set_fused(mode, lag)
+            s.init_states(C, cpz)
+            assert s.get_info(4) == (1 if mode else 0)
+            assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"]), (mode, lag)
+            r = s.resample(SIM_SEED, travel=True)
+            assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (mode, lag)
+            assert r["sum_tt_q16"] == ref["sum_tt_q16"], (mode, lag)
+            assert s.get_info(4) == (1 if mode == 1 else 0)      # after the bail-out the context keeps to two launches
+            assert s.get_info(2) == 4                            # ... and did not mistake it for an overflow
+
+
 @pytest.mark.parametrize("deal", ["interleaved", "contiguous"])
 def test_two_hip_ranks_on_one_gpu_sum_to_the_single_run(cpm, deal):
     """The sharded path with HIP ranks side by side: two processes, each with its own context on the one GPU and its share of the
