@@ -87,6 +87,12 @@ struct cpm_ctx {
     double *d_dist = nullptr;    // [Z][Z]
     double2 *d_tt = nullptr;          // [T][Z][Z] (mean, std) origin-major: what the grouped path's travel kernel gathers from (cpm_grouped.h)
     bool tt_valid = false;
+    // the same as sparse rows (cpm_grouped.h, k_tts_*), when the largest row fits LDS: what the travel kernel stages per (origin, hour)
+    uint2 *d_tts_words = nullptr;
+    uint32_t *d_tts_off = nullptr;
+    double2 *d_tts_cells = nullptr;
+    size_t tts_cells_cap = 0, tts_lds = 0;
+    bool tts_valid = false;
     double *d_pdrive_mean = nullptr;  // [T][Z] mean_sum of createpdrive (src/createpdrive.jl:10-21): depends on datamatrix and dist only,
     bool pdrive_mean_valid = false;   // so the model-selection sweep (p_min, p_max, e_drive vary) computes it once
     bool have_pdrive = false, have_cdf = false, have_dmat = false, have_dist = false;
@@ -292,6 +298,13 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
     tb.ckpt = c->d_ckpt;
     tb.p = c->d_p;
     tb.tt = c->d_tt;
+    if (c->tts_valid) {
+        tb.tts_words = c->d_tts_words;
+        tb.tts_off = c->d_tts_off;
+        tb.tts_cells = c->d_tts_cells;
+        tb.tts_W = static_cast<int>((c->Z + 31) / 32);
+        tb.tts_lds = c->tts_lds;
+    }
     tb.Z = static_cast<int>(c->Z);
     tb.Zp = c->Zp;
     tb.Zq = c->Zq;
@@ -369,6 +382,54 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
 
 int32_t finish_ivp(cpm_ctx *c);
 
+// The travel table as sparse rows (once per datamatrix, behind k_build_travel_table): kept when the largest row -- its bitmap words
+// and its non-zero cells -- fits 32 KB of LDS; the travel kernel then stages an origin's row instead of gathering cells from HBM.
+int32_t build_sparse_travel_rows(cpm_ctx *c)
+{
+    c->tts_valid = false;
+    const int64_t rows = c->T * c->Z;
+    const int W = static_cast<int>((c->Z + 31) / 32);
+    if (!c->d_tts_words) HIP_TRY(hipMalloc(&c->d_tts_words, sizeof(uint2) * static_cast<size_t>(rows) * W));
+    if (!c->d_tts_off) HIP_TRY(hipMalloc(&c->d_tts_off, sizeof(uint32_t) * static_cast<size_t>(rows + 1)));
+    uint32_t *d_count = nullptr;
+    HIP_TRY(hipMalloc(&d_count, sizeof(uint32_t) * static_cast<size_t>(rows) + 16));
+    struct Scratch {
+        uint32_t *&p;
+        ~Scratch() { dfree(p); }
+    } scratch{d_count};
+    uint32_t *d_max = d_count + rows;                                            // (+ total: 8 B behind it, 8-aligned or not: read as bytes)
+    unsigned long long *d_total = nullptr;
+    HIP_TRY(hipMalloc(&d_total, sizeof(unsigned long long)));
+    struct Scratch2 {
+        unsigned long long *&p;
+        ~Scratch2() { dfree(p); }
+    } scratch2{d_total};
+    hipLaunchKernelGGL(cpm::k_tts_words, dim3(static_cast<unsigned>(rows)), dim3(64), 0, c->stream, c->d_tt, c->d_tts_words, d_count, static_cast<int>(c->Z), W);
+    hipLaunchKernelGGL(cpm::k_tts_offsets, dim3(1), dim3(1024), 0, c->stream, d_count, c->d_tts_off, rows, d_max, d_total);
+    HIP_TRY(hipGetLastError());
+    uint32_t h_max = 0;
+    unsigned long long h_total = 0;
+    HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof h_max, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h_total, d_total, sizeof h_total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(h_max) * sizeof(double2);
+    if (lds > 32 * 1024 || h_total >= (1ull << 32)) return CPM_OK;  // dense rows: the travel kernel gathers from the dense table
+    if (h_total > c->tts_cells_cap) {
+        dfree(c->d_tts_cells);
+        c->tts_cells_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(double2) * std::max<size_t>(h_total, 1)));
+        c->tts_cells_cap = h_total;
+    }
+    hipLaunchKernelGGL(cpm::k_tts_cells, dim3(static_cast<unsigned>(rows)), dim3(64), 0, c->stream, c->d_tt, c->d_tts_words, c->d_tts_off, c->d_tts_cells,
+                       static_cast<int>(c->Z), W);
+    HIP_TRY(hipGetLastError());
+    c->tts_lds = lds;
+    c->tts_valid = true;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(c->d_tt);  // the dense table (Z x Z x T x 16 B: 2.1 GB at Melbourne's size) was only the way here; rebuilt with the next datamatrix
+    return CPM_OK;
+}
+
 // What a non-zero status word of a grouped step asks of the context.  Bit 2 (4): a placing block of the fused hour gave up waiting
 // for its sampler workgroups (a dispatch order the hand-off did not expect): two launches per hour from now on.  Bit 1 (2): a bucket
 // region or a run overflowed: twice the regions while the problem still fits.  true: the step can be repeated on the grouped path.
@@ -411,6 +472,8 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
                                dim3(cpm::kTtTile * 8), 0, c->stream, c->d_dm, c->d_tt, static_cast<int>(c->Z), static_cast<int>(c->T));
             HIP_TRY(hipGetLastError());
             c->tt_valid = true;
+            int32_t rc_tts = build_sparse_travel_rows(c);
+            if (rc_tts != CPM_OK) return rc_tts;
         }
         int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, travel, d_counts, c->cu_count,
                                       [&](int what) { prof_begin(c, what); }, [&](int what) { prof_end(c, what); }, g_last_error);
@@ -594,7 +657,8 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     }
     // development switches (tools/, A/B runs): the defaults of CPM_OPT_FUSED / CPM_OPT_FUSED_LAG
     if (const char *v = std::getenv("CPM_FUSED")) c->zg.fused_ok = std::atoi(v) != 0;
-    if (const char *v = std::getenv("CPM_FUSED_LAG")) c->zg.fused_lag = std::max(1, std::min(64, std::atoi(v)));
+    if (const char *v = std::getenv("CPM_HEAVY_X")) c->zg.heavy_x_seen = static_cast<uint32_t>(std::max(1, std::min(16, std::atoi(v))));
+    if (const char *v = std::getenv("CPM_FUSED_LAG")) c->zg.fused_lag = std::max(1, std::min(1 << 20, std::atoi(v)));
     *ctx_out = c;
     return CPM_OK;
 }
@@ -615,6 +679,9 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_dist);
     dfree(c->d_pdrive_mean);
     dfree(c->d_tt);
+    dfree(c->d_tts_words);
+    dfree(c->d_tts_off);
+    dfree(c->d_tts_cells);
     dfree(c->d_zone0);
     dfree(c->d_ztmp);
     dfree(c->d_rec);
@@ -646,7 +713,7 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->zg.fused_spin = value == 2 ? 0u : cpm::kFusedSpinLimit;  // 2: the placing blocks give up at once (tests of the bail-out)
         return CPM_OK;
     case CPM_OPT_FUSED_LAG:
-        if (value < 1 || value > 64) return fail(CPM_ERR_ARG, "fused lag %lld", (long long)value);
+        if (value < 1 || value > (1 << 20)) return fail(CPM_ERR_ARG, "fused lag %lld", (long long)value);
         c->zg.fused_lag = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE_KERNEL:
@@ -760,6 +827,7 @@ int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *d
     if (dist && !c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, dbytes));
     c->have_dmat = false;
     c->tt_valid = false;
+    c->tts_valid = false;
     c->pdrive_mean_valid = false;
     HIP_TRY(hipMemcpyAsync(c->d_dm, datamatrix, bytes, hipMemcpyHostToDevice, c->stream));
     if (dist) HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
@@ -789,6 +857,7 @@ static int32_t datamatrix_from_device_rows(cpm_ctx *c, const double *d_raw, int6
     if (!c->d_dm) HIP_TRY(hipMalloc(&c->d_dm, sizeof(double) * cells * 2));
     c->have_dmat = false;
     c->tt_valid = false;
+    c->tts_valid = false;
     c->pdrive_mean_valid = false;
     HIP_TRY(hipMemsetAsync(c->d_dm, 0, sizeof(double) * cells * 2, c->stream));  // zeros(number_zones, number_zones, T, 2) (:7)
     if (n == 0) {
@@ -1074,6 +1143,7 @@ int32_t cpm_synth_datamatrix(cpm_ctx *c, uint64_t table_seed, double density)
     if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * c->Z * c->Z));
     c->have_dmat = c->have_dist = false;
     c->tt_valid = false;
+    c->tts_valid = false;
     c->pdrive_mean_valid = false;
     hipLaunchKernelGGL(cpm::k_synth_datamatrix, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream,
                        c->d_dm, static_cast<int>(c->Z), static_cast<int>(c->T), table_seed, density);

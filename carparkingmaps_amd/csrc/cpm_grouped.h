@@ -197,6 +197,7 @@ struct GroupedArgs {
     int hour;                 // table hour of this launch (0-based): rare->nheavy[hour] counts its heavy buckets
     uint32_t *done_t;         // fused hour: [chunks] sampler workgroups of every chunk of origin zones that have handed their runs over
     int lag;                  // fused hour: the placing blocks of chunk j sit behind the sampler workgroups of chunk j + lag
+    uint32_t heavy_x;         // a bucket is heavy above heavy_x x the slots of its sampler workgroup (kHeavy; less once the heavy launch runs anyway)
     uint32_t spin_limit;      // fused hour: polls a placing block makes before it gives up (0: at once -- the tests' way into the bail-out)
     uint32_t cap, scap, idbits, gshift, step;
     // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
@@ -607,7 +608,7 @@ constexpr int kStage = CPM_STAGE;
 // overflow -- a quarter of the zones of the flat S4k tables hold a few cars more than CPT * BLOCK, the largest 2.5 x -- stays with
 // the overflow rounds of the first workgroup: handing it to a second launch cost more than it saved (profiles/round2_notes.md).
 constexpr uint32_t kHeavy = 4;
-constexpr int kHeavyCap = 4096;  // zones the heavy kernel can be handed in one hour (the rest stay with their first workgroup)
+constexpr int kHeavyCap = 65536;  // work items (chunks of heavy buckets) the heavy launch can be handed in one hour (zones that do not fit stay with their first workgroup)
 #ifndef CPM_WPS
 #define CPM_WPS 6  // waves per SIMD the register allocator must leave room for (see profiles/round1_notes.md, round2_notes.md)
 #endif
@@ -670,17 +671,27 @@ struct SampleLds {
 // A store / load of words that another workgroup of the SAME launch reads / has written (FUSED: the runs and run lengths, handed
 // from the sampler workgroups to the placing blocks of the fused hour): write-through past this XCD's L2 and past the reader's L1
 // (global_store / global_load ... sc1), as MI355X_MICROARCH.md's hand-off table prescribes.  !FUSED: plain.
+// (CPM_FUSED_ABLATE, tools/build_variants.sh: timing-only builds of the fused hour, results invalid -- 1: placing blocks return at once,
+//  2: placing blocks do not wait, 3: plain stores and no drain on the sampler side)
 template <bool FUSED>
 __device__ __forceinline__ void hand_store(uint32_t *p, uint32_t v)
 {
+#if defined(CPM_FUSED_ABLATE) && (CPM_FUSED_ABLATE == 3 || CPM_FUSED_ABLATE == 5)
+    *p = v;
+#else
     if constexpr (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
+#endif
 }
 template <bool FUSED>
 __device__ __forceinline__ uint32_t hand_load(const uint32_t *p)
 {
+#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE >= 4  // (4: plain loads in the placing blocks; 5: and plain stores, no drain)
+    return *p;
+#else
     if constexpr (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
+#endif
 }
 // FUSED: this workgroup's runs are complete -- every storing wave drains its stores, the workgroup meets, ONE lane counts the
 // workgroup in (agent-scope add on the counter of its chunk of origin zones; the placing blocks of that chunk poll it)
@@ -688,7 +699,9 @@ template <bool FUSED>
 __device__ __forceinline__ void hand_off_done(uint32_t *done_chunk, int tid)
 {
     if constexpr (FUSED) {
+#if !(defined(CPM_FUSED_ABLATE) && (CPM_FUSED_ABLATE == 3 || CPM_FUSED_ABLATE == 5))
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         if (tid == 0) __hip_atomic_fetch_add(done_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -732,7 +745,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     CPM_SSTAMP(1);
     // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
     // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
-    const bool heavy = n_all > kHeavy * CPT * BLOCK;
+    const bool heavy = n_all > a.heavy_x * CPT * BLOCK;
     if (tid == 0) {
         a.parking_t[z] = n_all;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         if (static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(a.rare->status, 2ull);  // the two ends of the bucket met: step invalid
@@ -740,13 +753,19 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         s_nstay = 0;
         uint32_t split = 0;
         if (heavy) {
+            // the bucket's chunks of CPT * BLOCK cars behind the first one become work items of the heavy launch: (zone, chunk)
             const GroupedRare *r = a.rare;
+            const uint32_t items = (n_all + CPT * BLOCK - 1) / (CPT * BLOCK) - 1u;
             atomicMax(&r->maxn[0], n_all);
-            const uint32_t idx = atomicAdd(r->nheavy + a.hour, 1u);
-            atomicMax(&r->maxn[1], idx + 1u);
-            if (GROUPED && r->parts > 1 && idx < r->hgrid) {
-                r->heavy_list[idx] = static_cast<uint32_t>(z);
-                split = 1;
+            const uint32_t idx = atomicAdd(r->nheavy + a.hour, items);
+            atomicMax(&r->maxn[1], idx + items);
+            if (GROUPED && r->parts > 1) {
+                if (idx + items <= r->hgrid) {
+                    for (uint32_t q = 0; q < items; ++q) r->heavy_list[idx + q] = static_cast<uint32_t>(z) | (q << 16);
+                    split = 1;
+                } else {  // no room for all of them: the bucket stays with this workgroup, and the slots it drew are void (not last hour's items)
+                    for (uint32_t q = 0; q < items && idx + q < r->hgrid; ++q) r->heavy_list[idx + q] = 0xFFFFFFFFu;
+                }
             }
         }
         s_split = split;
@@ -926,8 +945,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const int Z = a.Z;
     const GroupedRare *rare = a.rare;
     if (blockIdx.x >= min(rare->nheavy[a.hour], rare->hgrid)) return;  // (the list of this hour is shorter than the grid)
-    const int z = static_cast<int>(rare->heavy_list[blockIdx.x]);
-    const uint32_t q = blockIdx.y, nq = rare->parts - 1u;
+    const uint32_t item = rare->heavy_list[blockIdx.x];                 // one work item = one chunk of one listed zone
+    if (item == 0xFFFFFFFFu) return;                                    // (a slot drawn by a zone whose chunks did not all fit the list)
+    const int z = static_cast<int>(item & 0xFFFFu);
+    const uint32_t q = item >> 16;
     unsigned long long *status = rare->status;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr uint32_t L = CPT * BLOCK;
@@ -951,7 +972,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
     uint32_t nd = 0;
-    for (uint32_t start = start0; start < n; start += L * nq) {  // (block-uniform trips)
+    for (uint32_t start = start0, once = 0; once < 1u; ++once) {  // (one chunk per block)
         uint32_t id[CPT], dest[CPT], clo[CPT], khi[CPT];
         bool valid[CPT], drive[CPT], want[CPT], ok[CPT];
 #pragma unroll
@@ -1094,7 +1115,11 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     }
     if (tid == 0) s_any_long = 0;
     if (zs0 >= zs1) return;  // (uniform per block)
+#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE == 2
+    if constexpr (false) {
+#else
     if constexpr (FUSED) {
+#endif
         if (wave == 0) {
             bool ok = false;
             for (uint32_t spins = 0; spins < spin_limit; ++spins) {
@@ -1275,8 +1300,14 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
 // kernel is a chain of memory round trips that leaves the vector units idle, the sampler is bound by what it issues, and side by
 // side they fill each other's gaps (two INDEPENDENT resamples on two streams gain 24 % that way, profiles/round2_notes.md; this
 // is the same overlap inside one resample).  Block order: chunk c = kFusedChunk sampler workgroups, then the kGroups placing
-// blocks of chunk c - lag; a block only ever waits for blocks of LOWER index, which the dispatcher has started before it, so the
-// wait cannot deadlock however the blocks are placed; it is bounded all the same (grouped_place_body).  Chunk size + kGroups is a
+// blocks of chunk c - lag (lag >= the number of chunks, the default: all sampler workgroups, then all placing blocks); a block only
+// ever waits for blocks of LOWER index, which the dispatcher has started before it, so the wait cannot deadlock however the blocks
+// are placed; it is bounded all the same (grouped_place_body).
+// MEASURED (S4k, one box, profiles/round3_notes.md): two launches per hour 28.2 + 13.2 us; fused with lag 2 / 8 / 16 / 32 / 48 / 64:
+// 62 / 60 / 48 / 40 / 37.2 / 37.0 us.  A placing block that arrives before its samplers are done holds one of the CU's six block
+// slots while it waits -- every block of the launch carries the sampler's 106 scalar registers, so six blocks per CU is all there
+// is -- and the sampler, bound by what it issues, needs those slots to hide its latencies.  What pays is not the interleave but the
+// missing kernel boundary: placing blocks start in the slots the last sampler workgroups free, with no second launch ramp.  Chunk size + kGroups is a
 // multiple of 8: the placing blocks of one group share blockIdx % 8 = one XCD = one L2, as in the two-launch form (speed only).
 // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): runs and run lengths stored sc1 by the samplers, every storing wave
 // drains (s_waitcnt vmcnt(0)), workgroup barrier, one agent-scope add on the chunk's counter; the placing block polls that counter
@@ -1297,18 +1328,40 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         PlaceLds<kFusedThreads, 4, kFusedZpg> p;
     } u;
     constexpr int per = kFusedChunk + kGroups;
-    const int c = blockIdx.x / per, q = blockIdx.x % per;
     const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
-    if (q < kFusedChunk) {
-        const int z = c * kFusedChunk + q;
-        if (c >= nchunk || z >= a.Z) return;
-        grouped_sample_body<kFusedThreads, CPT, NQ, true, true>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(c) * kDoneStride);
+    int z = -1, g = 0, j = -1;  // the block's role: sampler workgroup of zone z, or placing block (g, j)
+    if (a.lag >= nchunk) {
+        // all sampler workgroups, then all placing blocks (chunk by chunk: the first ones find their runs long complete)
+        const int zr = (a.Z + 7) & ~7;  // (placing blocks of one group keep blockIdx % 8)
+        if (static_cast<int>(blockIdx.x) < zr) {
+            z = blockIdx.x;
+            if (z >= a.Z) return;
+        } else {
+            const int b = blockIdx.x - zr;
+            g = b % kGroups;
+            j = b / kGroups;
+        }
     } else {
-        const int j = c - a.lag;
-        if (j < 0) return;
+        const int c = blockIdx.x / per, q = blockIdx.x % per;
+        if (q < kFusedChunk) {
+            z = c * kFusedChunk + q;
+            if (c >= nchunk || z >= a.Z) return;
+        } else {
+            g = q - kFusedChunk;
+            j = c - a.lag;
+            if (j < 0) return;
+        }
+    }
+    if (z >= 0) {
+        grouped_sample_body<kFusedThreads, CPT, NQ, true, true>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(z / kFusedChunk) * kDoneStride);
+    } else {
+#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE == 1
+        return;
+#endif
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
-        grouped_place_body<kFusedThreads, 4, 2, kFusedZpg, true>(q - kFusedChunk, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap,
-                                                                  a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit);
+        grouped_place_body<kFusedThreads, 4, 2, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
+                                                                  a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride,
+                                                                  need, a.spin_limit);
     }
 }
 
@@ -1406,8 +1459,93 @@ __global__ __launch_bounds__(kTtTile * 8) void k_build_travel_table(const double
     }
 }
 
+// The travel table as SPARSE rows, for staging in LDS: real Uber Movement tables hold ~9 % of the (origin, destination, hour) cells
+// (README.md:302-310), so an origin's row of an hour is a bitmap of Z bits + ~200 cells of 16 B -- a few KB that the block of that
+// (origin, hour) brings into LDS once, instead of one scattered 16-B global load per driver (a line per lane: ~100 us of the ~300 us
+// the travel kernel took per resample at Z = 2,357).  Per row (t, o): words[w] = (bitmap of destinations 32 w .. 32 w + 31 with a
+// non-zero cell, number of non-zero cells of the row in front of word w), cells in destination order at cells[off[row] ...].
+// Built from the dense table in two passes of one wave per row (count, then fill); the offsets by one block.
+__global__ __launch_bounds__(64) void k_tts_words(const double2 *__restrict__ tt, uint2 *__restrict__ words, uint32_t *__restrict__ count, int Z, int W)
+{
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double2 *src = tt + row * Z;
+    uint32_t run = 0;
+    for (int d0 = 0; d0 < Z; d0 += 64) {
+        const int d = d0 + lane;
+        double2 c = make_double2(0.0, 0.0);
+        if (d < Z) c = src[d];
+        const unsigned long long m = ballot64(c.x != 0.0 || c.y != 0.0);
+        const uint32_t lo = static_cast<uint32_t>(m), hi = static_cast<uint32_t>(m >> 32);
+        if (lane == 0) {
+            words[row * W + d0 / 32] = make_uint2(lo, run);
+            if (d0 / 32 + 1 < W) words[row * W + d0 / 32 + 1] = make_uint2(hi, run + static_cast<uint32_t>(__popc(lo)));
+        }
+        run += static_cast<uint32_t>(__popcll(m));
+    }
+    if (lane == 0) count[row] = run;
+}
+// off[r] = sum of count[0 .. r-1], off[rows] = total; *max_out = largest row.  One block (rows is T x Z: ~10^5).
+__global__ __launch_bounds__(1024) void k_tts_offsets(const uint32_t *__restrict__ count, uint32_t *__restrict__ off, int64_t rows, uint32_t *__restrict__ max_out,
+                                                      unsigned long long *__restrict__ total_out)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ uint32_t pmax[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (rows + 1023) / 1024, r0 = tid * per, r1 = min(r0 + per, rows);
+    unsigned long long s = 0;
+    uint32_t mx = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+        s += count[r];
+        mx = max(mx, count[r]);
+    }
+    part[tid] = s;
+    pmax[tid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long acc = 0;
+        uint32_t m = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const unsigned long long v = part[k];
+            part[k] = acc;
+            acc += v;
+            m = max(m, pmax[k]);
+        }
+        *max_out = m;
+        *total_out = acc;
+    }
+    __syncthreads();
+    unsigned long long acc = part[tid];
+    for (int64_t r = r0; r < r1; ++r) {
+        off[r] = static_cast<uint32_t>(acc);
+        acc += count[r];
+    }
+    if (tid == 1023) off[rows] = static_cast<uint32_t>(acc);
+}
+__global__ __launch_bounds__(64) void k_tts_cells(const double2 *__restrict__ tt, const uint2 *__restrict__ words, const uint32_t *__restrict__ off,
+                                                  double2 *__restrict__ cells, int Z, int W)
+{
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double2 *src = tt + row * Z;
+    double2 *dst = cells + off[row];
+    for (int d0 = 0; d0 < Z; d0 += 64) {
+        const int d = d0 + lane;
+        if (d >= Z) continue;
+        const double2 c = src[d];
+        if (c.x != 0.0 || c.y != 0.0) {
+            const uint2 w = words[row * W + d / 32];
+            dst[w.y + static_cast<uint32_t>(__popc(w.x & ((1u << (d & 31)) - 1u)))] = c;
+        }
+    }
+}
+
 struct TravelArgs {
     const double2 *tt;            // [T][Z][Z] (mean, std), origin-major
+    const uint2 *tts_words;       // sparse rows (k_tts_*): [T*Z][W] (bitmap, cells in front), or null: gather from tt
+    const uint32_t *tts_off;      // [T*Z + 1] first cell of every row
+    const double2 *tts_cells;     // the non-zero cells, row by row
+    int W;                        // bitmap words per row
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
     size_t d_stride, c_stride;    // words between the runs / run lengths of consecutive hours (one launch for all hours), or 0
     int t0, gshift;               // hour of blockIdx.y = 0
@@ -1418,9 +1556,11 @@ struct TravelArgs {
 
 // one block (travel_block threads) per (origin zone, hour).  When the runs of all hours of a resample are kept (GroupedWork::history) ONE launch
 // at the end serves them all: 24 x fewer launches and a grid 24 x as deep (at Z = 2,357 an hourly grid is 1.15 rounds of blocks).
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restrict__ D, const uint32_t *__restrict__ cntg, int Z, uint32_t scap,
                                                         uint32_t idbits, TravelArgs tr)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char travel_lds[];  // SPARSE: the origin's row of this hour: W words, then its cells
     const int hour = tr.t0 + static_cast<int>(blockIdx.y);
     const uint32_t step = tr.step0 + blockIdx.y;
     D += tr.d_stride * blockIdx.y;
@@ -1431,6 +1571,14 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     __shared__ unsigned long long s_tt;
     const int z = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
+    uint2 *row_words = reinterpret_cast<uint2 *>(travel_lds);
+    double2 *row_cells = reinterpret_cast<double2 *>(travel_lds + ((static_cast<size_t>(tr.W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)));
+    if constexpr (SPARSE) {  // (requested first: lands under the prefix scan of the run lengths)
+        const size_t row = static_cast<size_t>(hour) * Z + z;
+        const uint32_t c0 = tr.tts_off[row], nc = tr.tts_off[row + 1] - c0;
+        for (int i = tid; i < tr.W; i += blockDim.x) row_words[i] = tr.tts_words[row * tr.W + i];
+        for (uint32_t i = tid; i < nc; i += blockDim.x) row_cells[i] = tr.tts_cells[c0 + i];
+    }
     if (tid < 64) {
         const uint32_t c = (lane < kGroups) ? min(cntg[static_cast<size_t>(z) * kGroups + lane], scap) : 0u;
         uint32_t incl = c;
@@ -1451,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
     // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
     constexpr int kTravelBatch = 4;
-    const double2 *tt_row = tr.tt + (static_cast<size_t>(hour) * Z + z) * Z;
+    const double2 *tt_row = SPARSE ? nullptr : tr.tt + (static_cast<size_t>(hour) * Z + z) * Z;
     for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
         uint32_t w[kTravelBatch], dest[kTravelBatch];
         bool live[kTravelBatch];
@@ -1471,7 +1619,16 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
 #pragma unroll
         for (int u = 0; u < kTravelBatch; ++u) {
             const bool moving = live[u] && dest[u] != static_cast<uint32_t>(z);
-            const double2 cell = moving ? tt_row[dest[u]] : make_double2(0.0, 0.0);
+            double2 cell = make_double2(0.0, 0.0);
+            if constexpr (SPARSE) {
+                if (moving) {
+                    const uint2 w = row_words[dest[u] >> 5];
+                    const uint32_t bit = 1u << (dest[u] & 31u);
+                    if (w.x & bit) cell = row_cells[w.y + static_cast<uint32_t>(__popc(w.x & (bit - 1u)))];
+                }
+            } else {
+                if (moving) cell = tt_row[dest[u]];
+            }
             mean[u] = cell.x;
             sd[u] = cell.y;
         }
@@ -1560,7 +1717,9 @@ inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
         }
     }
     const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
-    launch(k_grouped_hour<CPT, NQ>, dim3(static_cast<unsigned>((nchunk + a.lag) * (kFusedChunk + kGroups))), dim3(kFusedThreads), lds, stream, a);
+    const unsigned blocks = a.lag >= nchunk ? static_cast<unsigned>(((a.Z + 7) & ~7) + nchunk * kGroups)
+                                            : static_cast<unsigned>((nchunk + a.lag) * (kFusedChunk + kGroups));
+    launch(k_grouped_hour<CPT, NQ>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
 }
 // true when an instantiation exists for this problem (the common pack sizes; others take two launches per hour)
 inline bool fused_shape_ok(int Z, int Zq, int G)
@@ -1603,7 +1762,7 @@ inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, 
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(hgrid, parts - 1), dim3(kSampleBlock), lds, stream, a);
+    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(hgrid), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <int CPT>
@@ -1723,8 +1882,11 @@ struct GroupedWork {
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [Z*cap]: cached initial bucketing, ping-pong
     uint32_t *cnt0 = nullptr;                                    // [2][Z] the cached initial buckets: stayers (all cars after bucketing) | arrivals
     uint32_t *cnt = nullptr;                                     // [T+1][2][Z] per hour: stayers | arrivals of every bucket; then [T][chunks] the fused hour's hand-off counters
+    uint32_t heavy_x_seen = 2;                                   // the heavy threshold (x a workgroup's slots) once heavy buckets were seen: the heavy launch runs
+                                                                 // anyway then, and a bucket of 2-4 x the slots walked by ONE workgroup is the sampler's tail
     bool fused_ok = true;                                        // the fused hour is used (CPM_OPT_FUSED; cleared for good when a placing block gave up waiting)
-    int fused_lag = 2;                                           // chunks of sampler workgroups between a chunk and its placing blocks
+    int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
+                                                                 // every sampler workgroup first, then every placing block
     uint32_t fused_spin = kFusedSpinLimit;
     uint32_t *Dq = nullptr;                                      // [Z][kGroups][scap] packed drivers
     uint32_t *cntg = nullptr;                                    // [Z][kGroups] run lengths
@@ -1742,7 +1904,7 @@ struct GroupedWork {
     {
         const int64_t slots = static_cast<int64_t>(grouped_cpt((n + Z - 1) / std::max(Z, 1))) * kSampleBlock;
         parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(32, (largest_heavy_bucket + slots - 1) / slots)));
-        hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 8)) : 0;
+        hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 32)) : 0;  // (work items)
     }
 
     size_t fused_chunks() const { return static_cast<size_t>((Z + kFusedChunk - 1) / kFusedChunk); }
@@ -1830,6 +1992,11 @@ struct GroupedTables {
     const double *ckpt;      // [T][nck][Z] checkpoints of the running sums
     const double *p;         // [T][Z dest][Z origin] p_destin (reference layout)
     const double2 *tt;       // [T][Z][Z] travel table (k_build_travel_table) or nullptr
+    const uint2 *tts_words = nullptr;   // its sparse rows (k_tts_*), when a row fits LDS: what the travel kernel then stages per (origin, hour)
+    const uint32_t *tts_off = nullptr;
+    const double2 *tts_cells = nullptr;
+    int tts_W = 0;
+    size_t tts_lds = 0;      // bytes of the largest row (words + cells)
     int Z, Zp, Zq, T;
 };
 
@@ -1914,7 +2081,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         // hour T of a resample is sampled, never applied (src/resampling.jl:81-83): counts only -- unless its travel times are wanted,
         // which are computed from the runs
         const bool last_hour = !ivp && t + 1 == T;
-        const bool grouped = !last_hour || travel;
+        const bool grouped = !last_hour || travel || w.parts > 1;  // (heavy buckets: the grouped form splits them over workgroups, the plain one walks them)
         uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * 2 * Z;  // stayers; the arrivals Z words behind
         uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
         GroupedArgs a;
@@ -1946,6 +2113,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         const bool fuse = grouped && !last_hour && w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G);
         a.done_t = w.cnt + w.done_base() + static_cast<size_t>(t) * w.fused_chunks() * kDoneStride;
         a.lag = w.fused_lag;
+        a.heavy_x = w.parts > 1 ? w.heavy_x_seen : kHeavy;
         a.spin_limit = w.fused_spin;
         prof_begin(CPM_PROFILE_SAMPLER);
         if (fuse) grouped_launch_hour(a, mean, stream);
@@ -1965,6 +2133,10 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if (travel && grouped && !history) {
             TravelArgs tr{};
             tr.tt = tb.tt;
+            tr.tts_words = tb.tts_words;
+            tr.tts_off = tb.tts_off;
+            tr.tts_cells = tb.tts_cells;
+            tr.W = tb.tts_W;
             tr.tt_part = w.tt_part;
             tr.d_stride = tr.c_stride = 0;
             tr.t0 = t;
@@ -1973,7 +2145,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.cars = cars;
             tr.seed = seed;
             prof_begin(CPM_PROFILE_TRAVEL);
-            launch(k_grouped_travel, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
+            if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), tb.tts_lds, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
+            else launch(k_grouped_travel<false>, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             prof_end(CPM_PROFILE_TRAVEL);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone hour launch");
@@ -1981,6 +2154,10 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     if (history) {  // every hour's drivers are still in their runs: one launch
         TravelArgs tr{};
         tr.tt = tb.tt;
+        tr.tts_words = tb.tts_words;
+        tr.tts_off = tb.tts_off;
+        tr.tts_cells = tb.tts_cells;
+        tr.W = tb.tts_W;
         tr.tt_part = w.tt_part;
         tr.d_stride = w.run_words();
         tr.c_stride = w.len_words();
@@ -1990,7 +2167,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         tr.cars = cars;
         tr.seed = seed;
         prof_begin(CPM_PROFILE_TRAVEL);
-        launch(k_grouped_travel, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), tb.tts_lds, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        else launch(k_grouped_travel<false>, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
         prof_end(CPM_PROFILE_TRAVEL);
     }
     if (travel && !ivp) {  // the partial sums of k_grouped_travel -> the sum word of the count tensor

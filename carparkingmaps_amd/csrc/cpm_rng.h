@@ -124,6 +124,12 @@ __device__ __forceinline__ double exp_neg(double y)
 // Distributions.jl (absent, version unpinned); this is the build's own pinned sampler:
 // uniform proposal on the window, accept with exp(-(x-mu)^2 / (2 sigma^2)); attempt k draws
 // Philox stream stream0 + 2k; after 4096 rejections mu.
+// The acceptance test u2 <= exp_neg(y) is decided WITHOUT evaluating exp_neg wherever the alternating series brackets it:
+// 1 - y + y^2/2 - y^3/6 <= e^-y <= 1 - y + y^2/2 for y >= 0.  A draw at least 2^-45 below the lower bound is accepted, one at least
+// 2^-45 above the upper bound rejected -- 2^-45 is a hundred times the rounding error of either polynomial and of exp_neg (a few
+// 1e-16), so the decision is the one the full evaluation would take, bit for bit (the oracle always evaluates exp_neg: results are
+// compared exactly in tests/).  On the path y <= 0.5 (the window is +-0.1 mu, sigma >= 0.1 mu) and the undecided band is y^3/6 wide:
+// a wave needs exp_neg -- sixty f64 operations, half of the travel kernel's arithmetic -- for a few per cent of its attempts.
 __device__ __forceinline__ double truncnormal_pm10(uint64_t seed, uint64_t car, uint32_t step,
                                                    uint32_t stream0, double mu, double sigma)
 {
@@ -135,8 +141,23 @@ __device__ __forceinline__ double truncnormal_pm10(uint64_t seed, uint64_t car, 
         car_uniforms(seed, car, step, stream0 + 2 * k, u1, u2);
         double x = lo + w * u1;
         double d = x - mu;
-        double a = exp_neg((d * d) * inv2s2);
-        if (u2 <= a) return x;
+        const double y = (d * d) * inv2s2;
+        bool decided = false, accept = false;
+        if (y <= 1.0) {  // (false for NaN; y >= 0 otherwise)
+            const double h = 0.5 * (y * y);
+            const double upper = (1.0 - y) + h;
+            const double lower = upper - (h * y) * (1.0 / 3.0);
+            if (u2 <= lower - 0x1.0p-45) {
+                decided = true;
+                accept = true;
+            } else if (u2 > upper + 0x1.0p-45) {
+                decided = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(!decided) != 0ull) {  // (wave-uniform: most waves skip the evaluation altogether)
+            if (!decided) accept = u2 <= exp_neg(y);
+        }
+        if (accept) return x;
     }
     return mu;
 }

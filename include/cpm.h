@@ -70,7 +70,8 @@ extern "C" {
 #define CPM_OPT_FUSED 4         /* the grouped path's fused hour (sampler workgroups and the placing blocks of their drivers in ONE launch per hour):
                                    1 on (default), 0 off = two launches per hour, 2 = on with placing blocks that give up waiting at once (the
                                    tests' way into the bail-out: the step comes back with status bit 2 set and the context falls back to 0) */
-#define CPM_OPT_FUSED_LAG 5     /* chunks of 64 sampler workgroups between a chunk and its placing blocks in the fused launch (1..64, default 2) */
+#define CPM_OPT_FUSED_LAG 5     /* chunks of 64 sampler workgroups between a chunk and its placing blocks in the fused launch; at or above the number
+                                   of chunks (the default): every sampler workgroup first, then every placing block */
 #define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
 #define CPM_PROFILE_SAMPLER 0   /*   the sampler (default; every kernel family has one) */
 #define CPM_PROFILE_PLACE 1     /*   the grouped path's placing kernel */

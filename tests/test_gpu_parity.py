@@ -458,7 +458,7 @@ def test_fused_hour_equals_two_launches_per_hour(cpm, O, Z, cpz, T):
         p_dest = s.build_p_dest(2)
         ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
         s.set_kernel(5)
-        for mode, lag in [(1, 1), (0, None), (1, 2), (1, 7), (2, None)]:
+        for mode, lag in [(1, 1), (0, None), (1, 2), (1, 7), (1, 1 << 20), (2, None)]:
             s.set_fused(mode, lag)
             s.init_states(C, cpz)
             assert s.get_info(4) == (1 if mode else 0)

@@ -13,9 +13,8 @@ import _synth
 
 Z, T, cpz = 2357, 24, 1000
 C = Z * cpz
-dm, dist = _synth.datamatrix(Z, T)
 with cpm.Sampler(Z, T) as s:
-    s.set_datamatrix(dm, dist)
+    s.synth_datamatrix(0x5EED7AB1E)      # the Melbourne-shaped synthetic datamatrix, generated on the device
     s.build_p_drive(0.1, 0.9, 0.5, want=False)
     s.build_p_dest(2, want=False)
     s.init_states(C, cpz)
@@ -27,4 +26,11 @@ with cpm.Sampler(Z, T) as s:
         for _ in range(10):
             r = s.resample(0x5EEDCA125, travel=travel)
         dt = (time.perf_counter() - t0) / 10
+        if travel:                          # the travel kernel itself: hipEvent pairs on its launches
+            s.set_profile(True, stride=1, kernel=2)
+            for _ in range(5):
+                s.resample(0x5EEDCA125, travel=True)
+            ms = s.last_kernel_ms()
+            s.set_profile(False)
+            print(f"k_grouped_travel: {1e3 * sum(ms) / max(len(ms), 1):.1f} us per launch ({len(ms)} launches, one per resample when the runs of all hours are kept)")
         print(f"travel={travel}: {dt * 1e3:.3f} ms per resample, {C * T / dt:.3e} car-steps/s, drivers {int(r['driving'].sum())}, sum_tt {r['sum_tt_q16'] / 65536:.1f} s")
