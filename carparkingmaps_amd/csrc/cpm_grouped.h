@@ -260,6 +260,7 @@ constexpr size_t kRowLds = sizeof(double) * 2 * kRowTile * (kRowTile + 1) + size
 // itself (s_waitcnt vmcnt(32), 31, ... in front of the additions).  The last one or two tiles (the row's end and the pad) take a
 // plain path: rows beyond the table are clamped to its last row and their values unused.
 typedef uint32_t cpm_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cpm_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double row_load(__amdgpu_buffer_rsrc_t rows, uint32_t lane_off, uint32_t row_off)
 {
     const cpm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rows, lane_off, row_off, 0);
@@ -371,45 +372,71 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_build_rows(const double *__res
         row_sums(tile, src, lane, live, ck, last_o, Z, nt, err);
         return;
     }
-    // ---- the tiles out: lane = destination
+    // ---- the tiles out: a lane takes FOUR consecutive destinations of a row, sixteen lanes a row's 64, a wave four rows at a time: one
+    // 16-byte store per lane for the high words (and two for the f64 rows) -- with a lane per destination the launch was bound by the
+    // store instructions it issued (256 B each: 0.62 ms of 1.56 at S4k) and by ~45 instructions per destination for the guide (0.35 ms).
     const int nrow = min(kRowTile, Z - o0);
     const int sh = 32 - G;
     const int gw = pack_guide_words(G);
     const size_t rw = static_cast<size_t>(pack_row_words(Zq, G));
+    const int q16 = lane & 15, rr = lane >> 4;
+    const int mtop = (1 << G) + 7;  // the last guide entry (pad included)
     for (int k = 0; k < nt; ++k) {
         lds_barrier();
-        const int d = k * kRowTile + lane;
-        for (int r = wave - 1; r < nrow; r += kRowBlock / 64 - 1) {
-            const double c = tile[k & 1][r][lane];
-            const size_t row = static_cast<size_t>(t) * Z + o0 + r;
-            if (CDF && d < Zp) cdf[row * Zp + d] = c;
+        const int d = k * kRowTile + 4 * q16;  // the lane's first destination
+        for (int grp = wave - 1; grp * 4 < nrow; grp += kRowBlock / 64 - 1) {
+            const int r = grp * 4 + rr;
+            const bool row_live = r < nrow;
+            const int rc = row_live ? r : 0;  // (lanes of rows beyond the tile's last one go through the motions on row 0 and store nothing)
+            double c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = tile[k & 1][rc][4 * q16 + i];
+            const size_t row = static_cast<size_t>(t) * Z + o0 + rc;
+            if (CDF && row_live && d < Zp) {  // (Zp is a multiple of 16: a quad lies wholly inside or outside)
+                double2 *dst = reinterpret_cast<double2 *>(cdf + row * Zp + d);
+                dst[0] = make_double2(c[0], c[1]);
+                dst[1] = make_double2(c[2], c[3]);
+            }
             if (PACK) {
                 uint32_t *pack = rp + row * rw;
-                uint32_t h = kHiMax;
-                if (c < 1.0) h = static_cast<uint32_t>(floor(c * 0x1.0p32));  // exact scaling; c >= 0 (validated), +inf in the pad
+                uint32_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = kHiMax;
+                    if (c[i] < 1.0) h[i] = static_cast<uint32_t>(floor(c[i] * 0x1.0p32));  // exact scaling; c >= 0 (validated), +inf in the pad
+                }
 #ifndef CPM_ROWS_NO_HI  // (ablation builds, tools/build_variants.sh: what the write-out costs)
-                if (d < Zq) pack[gw + d] = h;
+                if (row_live && d < Zq) *reinterpret_cast<uint4 *>(pack + gw + d) = make_uint4(h[0], h[1], h[2], h[3]);  // (Zq: a multiple of 32)
 #endif
 #ifndef CPM_ROWS_NO_GUIDE
-                uint32_t hp = __shfl_up(h, 1, 64);
-                if (lane == 0) hp = prevh[r];
-                if (lane == 63) prevh[r] = h;  // (row r is this wave's in every tile)
-                int m0 = (d == 0) ? 0 : static_cast<int>(hp >> sh) + 1;
-                int m1 = (d < Z) ? static_cast<int>(h >> sh) : -1;
-                if (d == Z - 1) m1 = (1 << G) + 7;  // the entries no destination reaches, and the pad: Z - 1
-                int n = m1 - m0 + 1;
-                uint16_t *guide = reinterpret_cast<uint16_t *>(pack);
-                const uint16_t dv = static_cast<uint16_t>(d);
+                // guide: destination j owns the entries m with hi[j-1] < m << sh <= hi[j]; the lane's four destinations own a
+                // contiguous range [m_first, m_last] between them, entry m going to the first of them with m <= hi >> sh
+                uint32_t hp = __shfl_up(h[3], 1, 64);
+                if (q16 == 0) hp = prevh[rc];
+                if (q16 == 15 && row_live) prevh[rc] = h[3];  // (row r is this wave's in every tile)
+                int m1[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < n) guide[m0 + i] = dv;
+                for (int i = 0; i < 4; ++i)  // (Z - 1 owns the entries no destination reaches and the pad; what lies behind it owns nothing)
+                    m1[i] = (d + i < Z - 1) ? static_cast<int>(h[i] >> sh) : mtop;
+                const int m_first = (d == 0) ? 0 : static_cast<int>(hp >> sh) + 1;
+                const int m_last = (row_live && d < Z) ? m1[3] : -1;  // (m1 is non-decreasing)
+                uint16_t *guide = reinterpret_cast<uint16_t *>(pack);
+                auto owner = [&](int m, int a0, int a1, int a2, int dbase) {  // first of the four destinations with m <= its last entry
+                    return static_cast<uint16_t>(dbase + (m > a0 ? 1 : 0) + (m > a1 ? 1 : 0) + (m > a2 ? 1 : 0));
+                };
+                const int n = m_last - m_first + 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)  // (dense rows: one entry per four destinations on average)
+                    if (i < n) guide[m_first + i] = owner(m_first + i, m1[0], m1[1], m1[2], d);
                 unsigned long long more = ballot64(n > 4);  // long ranges (peaky rows, empty rows): the whole wave fills them
                 while (more) {
                     const int srcl = __builtin_ctzll(more);
                     more &= more - 1;
-                    const int s0 = __shfl(m0, srcl, 64) + 4, cnt = __shfl(n, srcl, 64) - 4;
-                    const uint16_t v = static_cast<uint16_t>(k * kRowTile + srcl);
-                    for (int i = lane; i < cnt; i += 64) guide[s0 + i] = v;
+                    const int s0 = __shfl(m_first, srcl, 64) + 4, cnt = __shfl(n, srcl, 64) - 4;
+                    const int a0 = __shfl(m1[0], srcl, 64), a1 = __shfl(m1[1], srcl, 64), a2 = __shfl(m1[2], srcl, 64);
+                    const int dbase = __shfl(d, srcl, 64);
+                    uint16_t *gsrc = reinterpret_cast<uint16_t *>(rp + (static_cast<size_t>(t) * Z + o0 + grp * 4 + (srcl >> 4)) * rw);
+                    for (int i = lane; i < cnt; i += 64) gsrc[s0 + i] = owner(s0 + i, a0, a1, a2, dbase);
                 }
 #endif
             }
@@ -662,10 +689,10 @@ __device__ unsigned long long *g_place_stamps = nullptr;  // [blocks][8], set by
 #endif
 
 // LDS of a sampler workgroup beside the row pack (one object: the fused kernel overlays it with the placing blocks')
-struct SampleLds {
-    uint32_t ndrive, nstay, split;
+struct alignas(16) SampleLds {
+    uint32_t stage[kGroups * kStage];  // (first: read back 16 bytes at a time)
     uint32_t gb[kGroups];
-    uint32_t stage[kGroups * kStage];
+    uint32_t ndrive, nstay, split, pad_;
 };
 
 // A store / load of words that another workgroup of the SAME launch reads / has written (FUSED: the runs and run lengths, handed
@@ -898,10 +925,23 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     lds_barrier();  // ranks, staged drivers and counters (all in LDS) are final; the stayers' stores need not have landed
     CPM_SSTAMP(6);
     if (GROUPED) {
-        // staged drivers -> their runs: 16 lanes per group, 64 B per store
-        for (int g = tid >> 4; g < kGroups; g += BLOCK / 16) {
+        // staged drivers -> their runs: 8 lanes per group, 16 bytes per lane (whole pieces: what lies beyond a run's length is never
+        // read).  One store instruction per thread; in the fused hour, where the runs are written through to memory (sc1), one fabric
+        // write per 16 bytes instead of one per dword.
+        static_assert(kStage % 4 == 0, "16-byte pieces");
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(runs, 0, static_cast<int>(kGroups * a.scap * 4u), 0x00020000);
+        for (int i = tid; i < kGroups * (kStage / 4); i += BLOCK) {
+            const int g = i / (kStage / 4), ch = i % (kStage / 4);
             const uint32_t lim = min(gb[g], static_cast<uint32_t>(kStage));
-            for (uint32_t i = tid & 15; i < lim; i += 16) hand_store<FUSED>(&runs[g * a.scap + i], stage[g * kStage + i]);
+            if (static_cast<uint32_t>(4 * ch) < lim) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(&stage[g * kStage + 4 * ch]);
+                cpm_u32x4 qv;
+                qv.x = q.x;
+                qv.y = q.y;
+                qv.z = q.z;
+                qv.w = q.w;
+                __builtin_amdgcn_raw_buffer_store_b128(qv, rs, (static_cast<uint32_t>(g) * a.scap + 4u * ch) << 2, 0, FUSED ? 16 : 0);  // (aux 16: sc1)
+            }
         }
         if (tid < kGroups) {
             const uint32_t c = gb[tid];
@@ -1093,9 +1133,14 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                                                    uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next, unsigned long long *status,
                                                    const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit)
 {
-    constexpr int kPlaceBlock = PB, kPlaceSeg = PB / 16;
-    constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;  // entries a block can hold in registers
-    constexpr int kRuns = KRUNS * kPlaceSeg;
+    // A run's first 32 entries are held by EIGHT lanes, four consecutive entries each: one 16-byte load per lane and run (two 4-byte
+    // loads per lane with sixteen lanes per run before: 12 load instructions per thread instead of 4, and in the fused hour, where
+    // the runs are read past this CU's L1 (sc1), a fabric request per dword instead of one per 16 bytes).
+    static_assert(KDEEP == 2 && KRUNS % 2 == 0, "written for 32 register entries per run");
+    constexpr int kPlaceBlock = PB, kPlaceSeg = PB / 8;    // 8-lane segments: one run each per pass
+    constexpr int KR = KRUNS / 2;                          // runs per lane segment (= passes)
+    constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;    // entries a block can hold in registers
+    constexpr int kRuns = KR * kPlaceSeg;
     constexpr int kSurplusBatch = 4;
     uint32_t(&bins)[ZPG] = pl.bins, (&tbins)[ZPG] = pl.tbins, (&delta)[ZPG] = pl.delta;
     uint32_t(&wsum)[PB / 64] = pl.wsum, &s_total = pl.total;
@@ -1105,7 +1150,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     const int zg0 = g * zpg;
     const int nzl = max(0, min(zpg, Z - zg0));
     const int zs0 = j * zps, zs1 = min(Z, zs0 + zps);
-    const int sub = tid >> 4, l16 = tid & 15;
+    const int sub = tid >> 3, l8 = tid & 7;
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
     CPM_PSTAMP_DECL;
     CPM_PSTAMP(0);
@@ -1138,34 +1183,42 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
             return;
         }
     }
-    uint32_t c[KRUNS], v[KRUNS][KDEEP], r[KRUNS][KDEEP];
+    uint32_t c[KR], v[KR][4], r[KR][4];
+    // (the block's runs behind one buffer descriptor: zone zs0's group-0 run is byte 0; < 2^32 bytes for every region size)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(D) + static_cast<size_t>(zs0) * kGroups * scap, 0,
+        static_cast<int>(static_cast<uint32_t>(zs1 - zs0) * kGroups * scap * 4u), 0x00020000);
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {  // (nothing here depends on a loaded value: all 12 requests leave before the first wait)
+    for (int k = 0; k < KR; ++k) {  // (nothing here depends on a loaded value: every request leaves before the first wait)
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
         c[k] = hand_load<FUSED>(&cntg[run]);
-#pragma unroll
-        for (int d = 0; d < KDEEP; ++d) v[k][d] = hand_load<FUSED>(&D[run * scap + l16 + 16 * d]);  // scap >= 16 * KDEEP; beyond c[k]: stale, masked
+        const cpm_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(zc - zs0) * kGroups + g) * scap + 4u * l8) << 2, 0,
+                                                                  FUSED ? 16 : 0);  // (aux 16: sc1)  scap >= 32; beyond c[k]: stale, masked
+        v[k][0] = q.x;
+        v[k][1] = q.y;
+        v[k][2] = q.z;
+        v[k][3] = q.w;
     }
     lds_barrier();
     CPM_PSTAMP(1);
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
+    for (int k = 0; k < KR; ++k) {
         c[k] = min(c[k], scap);  // (beyond scap only when the heavy kernel flagged an overflow: the step is repeated)
         if (zs0 + sub + k * kPlaceSeg >= zs1) c[k] = 0;
     }
     // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
+    for (int k = 0; k < KR; ++k) {
 #pragma unroll
-        for (int d = 0; d < KDEEP; ++d) {
+        for (int d = 0; d < 4; ++d) {
             r[k][d] = 0;
-            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
+            if (static_cast<uint32_t>(4 * l8 + d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
         }
     }
-    if (l16 == 0) {
+    if (l8 == 0) {
 #pragma unroll
-        for (int k = 0; k < KRUNS; ++k) {
+        for (int k = 0; k < KR; ++k) {
             const uint32_t surplus = c[k] > 16u * KDEEP ? c[k] - 16u * KDEEP : 0u;
             lstart[sub + k * kPlaceSeg] = surplus;
             if (surplus) s_any_long = 1u;
@@ -1237,10 +1290,10 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     CPM_PSTAMP(5);
     // pass B: the entries held in registers go to their place in the sorted list
 #pragma unroll
-    for (int k = 0; k < KRUNS; ++k) {
+    for (int k = 0; k < KR; ++k) {
 #pragma unroll
-        for (int d = 0; d < KDEEP; ++d)
-            if (static_cast<uint32_t>(l16 + 16 * d) < c[k]) {
+        for (int d = 0; d < 4; ++d)
+            if (static_cast<uint32_t>(4 * l8 + d) < c[k]) {
                 const uint32_t dl = v[k][d] >> idbits;
                 const uint32_t li = bins[dl] + r[k][d];
                 sorted_ids[li] = v[k][d] & idmask;
