@@ -118,17 +118,35 @@ def pmc_traffic(Z, cars_per_gpu, skew):
     if not os.path.exists(path):
         return {}, None
     out = {}
+    # entries are "<kernel> @grid=<threads>": the side records launch the same kernels at other sizes (Z = 2,357) and on other
+    # tables (--skew), so a kernel is taken at THIS workload's grid, and the two-launch kernels only from a run that had no fused hour
+    grids = {"hour": None, "sampler": Z * 256, "place": None, "build_rows": ((Z + 63) // 64) * 24 * 256}
+    grids["build_rows_full"] = grids["build_rows"]
     for k, v in json.load(open(path)).items():
         if v.get("launches", 0) <= 0:
             continue
-        if "k_grouped_hour" in k:                         # the fused hour: sampler workgroups + placing blocks in one launch
-            out["hour"] = v["hbm_bytes_per_launch"]
-        elif "k_grouped_sample" in k and ", true>(" in k:   # (the grouped form; the plain form only runs hour 24)
-            out["sampler"] = v["hbm_bytes_per_launch"]
-        elif "k_grouped_place" in k:
-            out["place"] = v["hbm_bytes_per_launch"]
-        elif "k_build_rows<false, true>" in k or "k_build_rows<0, 1>" in k:
-            out["build_rows"] = v["hbm_bytes_per_launch"]
+        name, _, grid = k.partition(" @grid=")
+        grid = int(grid) if grid else None
+        if "k_grouped_hour<4, 5>" in name:                   # the fused hour at Z = 4,096 (NQ = 5): sampler workgroups + placing blocks
+            key = "hour"
+        elif "k_grouped_sample<" in name and ", true>(" in name:   # (the grouped form; the plain form only runs hour 24)
+            key = "sampler"
+        elif "k_grouped_place" in name:
+            key = "place"
+        elif "k_build_rows<false, true>" in name or "k_build_rows<0, 1>" in name:
+            key = "build_rows"
+        elif "k_build_rows<true, true>" in name or "k_build_rows<1, 1>" in name:
+            key = "build_rows_full"
+        else:
+            continue
+        if grids[key] is not None and grid is not None and grid != grids[key]:
+            continue
+        if key not in out or v["launches"] > out[key][1]:
+            out[key] = (v["hbm_bytes_per_launch"], v["launches"])
+    out = {k: v[0] for k, v in out.items()}
+    if "hour" in out:                                        # (then the two-launch kernels in the file ran on the skewed tables)
+        out.pop("sampler", None)
+        out.pop("place", None)
     return out, "profiles/" + PROFILE_TAG + "_traffic.json"
 
 
@@ -256,7 +274,7 @@ def table_build_record(s, Z, traffic):
         nbytes = Z * Z * T * 8 + T * Z * rw * 4 + T * Z * 8 + T * nck * Z * 8 + (T * Z * ((Z + 15) // 16 * 16) * 8 if full else 0)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out[name] = {"ms": ms, "algorithmic_bytes": nbytes, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-                     "traffic": traffic.get("build_rows") if not full else None}
+                     "traffic": traffic.get("build_rows_full" if full else "build_rows")}
     s.refresh_tables(with_f64_cdf=False)
     out["what"] = ("p_destin (Z x Z x T f64, reference layout) -> row packs (guide + CDF high words) + row totals + checkpoints in ONE "
                    "launch (k_build_rows; sequential f64 running sum of src/resampling.jl:39); wall time of the blocking call, median of 5; "
@@ -274,6 +292,8 @@ def per_dataset_record(env):
     s.synth_datamatrix(TABLE_SEED)
 
     def once():
+        s.synth_datamatrix(TABLE_SEED)       # a NEW dataset every time: nothing derived from the last one is reused (createpdrive's
+        s.sync()                             # cached Z x Z x T pass, the sparse travel rows); its generation is not timed
         t0 = time.perf_counter()
         s.build_p_drive(0.1, 0.9, 0.5, want=False)
         s.sync()
@@ -283,21 +303,25 @@ def per_dataset_record(env):
         s.init_states(C, cpz)
         s.solve_ivp(SIM_SEED, want=False)
         t3 = time.perf_counter()
-        r = s.resample(SIM_SEED, travel=True)
+        r = s.resample(SIM_SEED, travel=True)    # (builds the dataset's sparse travel rows first)
         t4 = time.perf_counter()
-        return (t1 - t0, t2 - t1, t3 - t2, t4 - t3), r
+        s.resample(SIM_SEED, travel=True)
+        t5 = time.perf_counter()
+        return (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4), r
     once()
     runs = [once() for _ in range(3)]
-    med = [statistics.median(r[0][k] for r in runs) * 1e3 for k in range(4)]
+    med = [statistics.median(r[0][k] for r in runs) * 1e3 for k in range(5)]
     r = runs[-1][1]
     assert (r["parking"].sum(axis=0) == C).all()
     s.close()
-    total = sum(med)
+    total = sum(med[:4])
     cells = Z * Z * T * 8
-    return {"what": "one dataset of main.jl:79-95 at Melbourne's shape (Z = 2,357 x 1,000 cars/zone, synthetic sparse datamatrix resident in "
-                    "HBM): createpdrive, createpdestin (weights, row sums, row tables), initializestates + 23-hour IVP, 24-hour resample "
-                    "with travel times and the count tensor on the host; blocking calls, median of 3",
-            "createpdrive_ms": med[0], "createpdestin_ms": med[1], "ivp_ms": med[2], "resample_ms": med[3], "total_ms": total,
+    return {"what": "one NEW dataset of main.jl:79-95 at Melbourne's shape (Z = 2,357 x 1,000 cars/zone, synthetic sparse datamatrix "
+                    "generated in HBM before the clock starts): createpdrive (Z x Z x T pass included), createpdestin (weights, row sums, "
+                    "row tables), initializestates + 23-hour IVP, 24-hour resample with travel times (the dataset's travel rows are "
+                    "built inside the first one) and the count tensor on the host; blocking calls, median of 3",
+            "createpdrive_ms": med[0], "createpdestin_ms": med[1], "ivp_ms": med[2], "resample_ms": med[3],
+            "resample_again_ms": med[4], "total_ms": total,
             "tables_algorithmic_bytes": int(cells + Z * Z * 8 + 3 * cells + cells + T * Z * pack_row_words(Z) * 4),
             "value": C * (2 * T - 1) / (total * 1e-3), "unit": "car-steps/s"}
 

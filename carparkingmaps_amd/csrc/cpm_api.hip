@@ -109,6 +109,7 @@ struct cpm_ctx {
     int64_t *d_counts = nullptr;  // [2*T*Z + 2]
     int64_t *h_counts = nullptr;  // pinned twin: the blocking calls bring the whole tensor (status word included) over in one copy
     int *d_err = nullptr;
+    int *h_err = nullptr;         // pinned twin of the validation flag
     // zone-bucket paths
     cpm::ExactWork zx;
     cpm::GroupedWork zg;
@@ -177,9 +178,10 @@ int32_t ensure_rec(cpm_ctx *c)
 
 int32_t check_err_flag(cpm_ctx *c, const char *what, int32_t code)
 {
-    int h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // (into pinned memory: a copy into pageable memory goes through the runtime's staging path -- ~1 ms per call, measured on createpdestin)
+    HIP_TRY(hipMemcpyAsync(c->h_err, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const int h = *c->h_err;
     if (h) {
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         return fail(code, "%s", what);
@@ -644,6 +646,7 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     if (c->cu_count <= 0) c->cu_count = 256;
     hipError_t e = hipMalloc(&c->d_err, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counts), sizeof(int64_t) * static_cast<size_t>(2 * T * Z + 2));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_status), 2 * sizeof(long long));
@@ -689,6 +692,7 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_err);
     c->zx.release();
     c->zg.release();
+    if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_ivp_status) (void)hipHostFree(c->h_ivp_status);

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pair ${BENCH_ARGS}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pair ${BENCH_ARGS}"  # (the side records stay in: table_build, per_dataset and skewed put their kernels into the same trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo trace done >> $OUT/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1

@@ -38,7 +38,8 @@ def pmc(sub):
     acc = defaultdict(lambda: defaultdict(list))
     if f:
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            # (one entry per kernel AND grid: the side records of the bench launch the same kernels at other sizes)
+            acc[f'{r["Kernel_Name"]} @grid={r["Grid_Size"]}'][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -60,7 +61,8 @@ for k in sorted(set(fetch) | set(write)):
     hr = (sum(hit) / (sum(hit) + sum(miss))) if hit and (sum(hit) + sum(miss)) else float("nan")
     total = 2 * fa * 1024 + wa * 1024
     traffic[k] = {"launches": len(f), "fetch_kib": fa, "write_kib": wa, "hbm_bytes_per_launch": total, "l2_hit_rate": hr}
-    lines.append(f"| `{k[:60]}` | {len(f)} | {fa:.0f} | {wa:.0f} | {total:.3e} | {hr:.3f} |")
+    kn, _, grid = k.partition(" @grid=")
+    lines.append(f"| `{kn[:60]}` grid {grid} | {len(f)} | {fa:.0f} | {wa:.0f} | {total:.3e} | {hr:.3f} |")
 sweep = one("sweep/**/*_kernel_stats.csv")
 if sweep:
     shutil.copy(sweep, os.path.join(dst, f"{name}_sweep_kernel_stats.csv"))
