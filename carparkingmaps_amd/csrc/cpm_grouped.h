@@ -216,6 +216,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Votes on a condition that already is a lane mask: HIP's __ballot / __any take an int, and hipcc materialises the mask as 0 / 1 in
 // a VGPR and compares it again (two VALU instructions per vote; the sampler is bound by what it issues).
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Inclusive prefix sum over the 64 lanes of a wave in the vector ALU (DPP: shifts inside a row of 16 lanes, then the last lane of
+// a row broadcast to the rows behind it): six dependent additions and no LDS instruction.  __shfl_up is a ds_bpermute per step --
+// a round trip through the LDS pipeline, which the sampler workgroups sharing the CU keep busy: the placing blocks' scan of their
+// histogram took 4.9 k cycles of a 13 k-cycle block with it (tools/hour_stamps.py).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+    int v = static_cast<int>(x);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1 (lanes without a source keep the 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return static_cast<uint32_t>(v);
+}
 __device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // p[i] = v with the address as uniform base + 32-bit BYTE offset (i x 4 B < 2^32: a bucket region): the store takes the base from
 // scalar registers and one VGPR instead of a 64-bit address pair built per store
@@ -434,12 +449,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_build_rows(const double *__res
                 // took eight rounds per pass on Melbourne-shaped tables: 1.5 ms for the kernel against 0.6 on dense ones.)
                 if (ballot64(n > 4)) {
                     const int extra = max(n - 4, 0);
-                    int incl = extra;
-#pragma unroll
-                    for (int sft = 1; sft < 64; sft <<= 1) {
-                        const int up = __shfl_up(incl, sft, 64);
-                        if (lane >= sft) incl += up;
-                    }
+                    const int incl = static_cast<int>(wave_incl_scan(static_cast<uint32_t>(extra)));
                     const int total = __shfl(incl, 63, 64);
                     for (int e = lane; e - lane < total; e += 64) {
                         int src = 0;  // first lane whose running total lies above e
@@ -688,7 +698,14 @@ __device__ unsigned long long *g_place_stamps = nullptr;  // [blocks][8], set by
 #define CPM_STAMP_NONE \
     do {               \
     } while (0)
-#ifdef CPM_STAMP_SAMPLER  // (the same side buffer, filled by the sampler instead of the placing kernel: -DCPM_DIAGNOSTIC -DCPM_STAMP_SAMPLER)
+#if defined(CPM_STAMP_BOTH)  // (-DCPM_DIAGNOSTIC -DCPM_STAMP_BOTH: both roles of the fused hour, one row per block of the launch; tools/hour_stamps.py)
+#define CPM_SSTAMP_DECL CPM_STAMP_DECL_IMPL
+#define CPM_SSTAMP(k) CPM_STAMP_IMPL(k)
+#define CPM_SSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
+#define CPM_PSTAMP_DECL CPM_STAMP_DECL_IMPL
+#define CPM_PSTAMP(k) CPM_STAMP_IMPL(k)
+#define CPM_PSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
+#elif defined(CPM_STAMP_SAMPLER)  // (the same side buffer, filled by the sampler instead of the placing kernel: -DCPM_DIAGNOSTIC -DCPM_STAMP_SAMPLER)
 #define CPM_SSTAMP_DECL CPM_STAMP_DECL_IMPL
 #define CPM_SSTAMP(k) CPM_STAMP_IMPL(k)
 #define CPM_SSTAMP_FLUSH CPM_STAMP_FLUSH_IMPL
@@ -973,6 +990,9 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         }
     }
     CPM_SSTAMP(7);
+#ifdef CPM_STAMP_BOTH
+    if constexpr (FUSED)  // (only the fused hour's blocks: the buffer then holds the last fused launch of the resample)
+#endif
     CPM_SSTAMP_FLUSH;
     hand_off_done<FUSED>(done_chunk, tid);
 }
@@ -1246,9 +1266,10 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
     auto surplus_entry = [&](uint32_t e) -> uint32_t {
         int r = 0;
+        constexpr int kTop = kRuns <= 64 ? 32 : kRuns <= 128 ? 64 : kRuns <= 256 ? 128 : 256;  // largest power of two < kRuns ... (kRuns need not be one)
 #pragma unroll
-        for (int step = kRuns / 2; step > 0; step >>= 1)
-            if (lstart[r + step] <= e) r += step;
+        for (int step = kTop; step > 0; step >>= 1)
+            if (r + step < kRuns && lstart[r + step] <= e) r += step;
         const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + (r % kPlaceSeg) + (r / kPlaceSeg) * kPlaceSeg = zs0 + r)
         return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - lstart[r])]);
     };
@@ -1257,11 +1278,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     if (any_long) {
         // exclusive scan of the surplus lengths (kRuns <= kPlaceBlock values, one per thread), then the histogram of the surplus
         const uint32_t len = tid < kRuns ? lstart[tid] : 0u;
-        uint32_t incl = len;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
+        const uint32_t incl = wave_incl_scan(len);
         if (lane == 63) wsum[wave] = incl;
         lds_barrier();
         uint32_t before = 0;
@@ -1288,11 +1305,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     if (cr + ct) base = atomicAdd(&cnt_a_next[zg0 + tid], cr + ct);
     uint32_t first;
     {
-        uint32_t incl = cr;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
+        const uint32_t incl = wave_incl_scan(cr);
         if (lane == 63) wsum[wave] = incl;
         lds_barrier();
         uint32_t before = 0;
@@ -1325,10 +1338,20 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     lds_barrier();
     // the sorted list out: consecutive lanes, consecutive slots of one bucket ...
     const uint32_t total = s_total;
-    for (uint32_t i = tid; i < total; i += kPlaceBlock) {
-        const uint32_t dl = sorted_zone[i];
-        const uint32_t p = delta[dl] + i;
-        if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = sorted_ids[i];  // arrivals fill a region from its top
+    constexpr int kOutBatch = 4;  // (a thread's LDS reads of a batch are in flight together: zone, then delta + id, then the store)
+    for (uint32_t i0 = tid; i0 < total; i0 += kOutBatch * kPlaceBlock) {
+        uint32_t dl[kOutBatch], p[kOutBatch], idv[kOutBatch];
+#pragma unroll
+        for (int u = 0; u < kOutBatch; ++u) dl[u] = sorted_zone[min(i0 + u * kPlaceBlock, total - 1u)];  // (total > 0 inside the loop)
+#pragma unroll
+        for (int u = 0; u < kOutBatch; ++u) {
+            p[u] = delta[dl[u]] + i0 + u * kPlaceBlock;
+            idv[u] = sorted_ids[min(i0 + u * kPlaceBlock, total - 1u)];
+        }
+#pragma unroll
+        for (int u = 0; u < kOutBatch; ++u)
+            if (i0 + u * kPlaceBlock < total && p[u] < cap)
+                ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
     for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {
@@ -1344,7 +1367,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
             }
     }
     CPM_PSTAMP(7);
-#if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER)
+#if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER) && !defined(CPM_STAMP_BOTH)
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
 #endif
     CPM_PSTAMP_FLUSH;
@@ -1382,7 +1405,11 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
 // drains (s_waitcnt vmcnt(0)), workgroup barrier, one agent-scope add on the chunk's counter; the placing block polls that counter
 // with relaxed agent-scope loads and reads the runs with sc1 loads.  Everything else crosses a kernel boundary as before: the
 // buckets the placing blocks fill are read by the NEXT launch.
-constexpr int kFusedChunk = 64;  // origin zones per chunk = runs a 256-thread placing block takes (16 lanes per run, KRUNS = 4)
+#ifndef CPM_FUSED_KRUNS
+#define CPM_FUSED_KRUNS 4
+#endif
+constexpr int kFusedKruns = CPM_FUSED_KRUNS;
+constexpr int kFusedChunk = 16 * kFusedKruns;  // origin zones per chunk = runs a 256-thread placing block takes (8 lanes per run, KRUNS / 2 passes)
 constexpr int kDoneStride = 32;  // words between the hand-off counters of consecutive chunks: a 128-B line each (64 adds and the polls of 32
                                  // placing blocks per counter; with all of an hour's counters in two lines every add and every poll of the
                                  // launch queued at one memory channel: 300 us per launch instead of 30)
@@ -1394,7 +1421,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
     extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
     __shared__ union {
         SampleLds s;
-        PlaceLds<kFusedThreads, 4, kFusedZpg> p;
+        PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg> p;
     } u;
     constexpr int per = kFusedChunk + kGroups;
     const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
@@ -1428,7 +1455,10 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         return;
 #endif
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
-        grouped_place_body<kFusedThreads, 4, 2, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
+#ifdef CPM_PLACE_PRIO
+        __builtin_amdgcn_s_setprio(CPM_PLACE_PRIO);
+#endif
+        grouped_place_body<kFusedThreads, kFusedKruns, 2, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
                                                                   a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride,
                                                                   need, a.spin_limit);
     }
@@ -1770,7 +1800,7 @@ inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2
 // the fused hour (k_grouped_hour): (chunks + lag) x (kFusedChunk sampler workgroups + kGroups placing blocks)
 inline size_t fused_lds_bytes(int Zq, int G)
 {
-    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(6) * 4 * 2 * kFusedThreads);
+    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(6) * kFusedKruns * 2 * kFusedThreads);
 }
 template <int CPT, int NQ>
 inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
