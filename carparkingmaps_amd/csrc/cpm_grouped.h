@@ -1529,6 +1529,8 @@ inline int travel_block(int64_t mean_bucket, bool heavy_seen)
     if (heavy_seen || mean_bucket > 4096) return 256;
     return mean_bucket > 2048 ? 128 : 64;
 }
+// LDS of a travel block on sparse rows: the largest row, then eight (cell, car) list entries per thread
+inline size_t travel_lds_bytes(size_t row_bytes, int block) { return row_bytes + static_cast<size_t>(8) * 8 * block; }
 
 // The travel kernel gathers (mean, std) of its drivers' (origin, destination, hour) cells.  In the reference's datamatrix layout
 // [2][T][dest][origin] the two values lie Z*Z*T*8 B apart and consecutive destinations of one origin Z*8 B apart: two cache lines per
@@ -1633,8 +1635,11 @@ __global__ __launch_bounds__(64) void k_tts_cells(const double2 *__restrict__ tt
         if (d >= Z) continue;
         const double2 c = src[d];
         if (c.x != 0.0 || c.y != 0.0) {
+            // a cell as the travel kernel uses it: (mean, 1 / (2 sigma^2)) with sigma = std, or a tenth of the mean where the data hold
+            // no std (src/resampling.jl:65-67) -- the division of the sampler (truncnormal_pm10), done once per cell instead of per driver
             const uint2 w = words[row * W + d / 32];
-            dst[w.y + static_cast<uint32_t>(__popc(w.x & ((1u << (d & 31)) - 1u)))] = c;
+            const double s1 = (c.y == 0) ? 0.1 * c.x : c.y;
+            dst[w.y + static_cast<uint32_t>(__popc(w.x & ((1u << (d & 31)) - 1u)))] = make_double2(c.x, truncnormal_inv2s2(s1));
         }
     }
 }
@@ -1643,8 +1648,9 @@ struct TravelArgs {
     const double2 *tt;            // [T][Z][Z] (mean, std), origin-major
     const uint2 *tts_words;       // sparse rows (k_tts_*): [T*Z][W] (bitmap, cells in front), or null: gather from tt
     const uint32_t *tts_off;      // [T*Z + 1] first cell of every row
-    const double2 *tts_cells;     // the non-zero cells, row by row
+    const double2 *tts_cells;     // the non-zero cells, row by row: (mean, 1 / (2 sigma^2))
     int W;                        // bitmap words per row
+    uint32_t list_off;            // sparse rows: byte offset of the threads' driver lists in the block's LDS (behind the largest row)
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
     size_t d_stride, c_stride;    // words between the runs / run lengths of consecutive hours (one launch for all hours), or 0
     int t0, gshift;               // hour of blockIdx.y = 0
@@ -1695,10 +1701,81 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     const uint32_t total = prefix[kGroups];
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
     long long tt = 0;
+    if constexpr (SPARSE) {
+        // Batches of kTravelList drivers per thread.  Front half, all lanes together: the run entries (requested together), the
+        // destinations, the cell of each in the staged row; drivers inside the zone are done (300 s), the others go on the thread's
+        // list in LDS: (cell, car).  Back half: every lane works its list off, ONE attempt of the rejection sampler per trip whatever
+        // driver it is at -- a wave leaves when its slowest lane has made the attempts of all ITS drivers (~1.2 per driver), not the
+        // largest number of attempts among 64 drivers, driver after driver (3.2 of which 1.2 were needed: the kernel was 2/3 idle lanes).
+        constexpr int kTravelList = 8;
+        constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+        uint2 *list = reinterpret_cast<uint2 *>(travel_lds + tr.list_off);
+        const uint32_t nthr = blockDim.x;
+        for (uint32_t base = 0; base < total; base += kTravelList * nthr) {
+            uint32_t w[kTravelList], gq[kTravelList];
+            bool live[kTravelList];
+#pragma unroll
+            for (int u = 0; u < kTravelList; ++u) {
+                const uint32_t i = base + tid + u * nthr;
+                live[u] = i < total;
+                uint32_t g = 0;
+#pragma unroll
+                for (int step = kGroups / 2; step > 0; step >>= 1)
+                    if (prefix[g + step] <= i) g += step;
+                g = live[u] ? g : 0u;
+                gq[u] = g;
+                w[u] = live[u] ? D[(static_cast<size_t>(z) * kGroups + g) * scap + (i - prefix[g])] : 0u;
+            }
+            uint32_t n = 0;
+#pragma unroll
+            for (int u = 0; u < kTravelList; ++u) {
+                if (!live[u]) continue;
+                const uint32_t dest = (gq[u] << tr.gshift) + (w[u] >> idbits);
+                if (dest == static_cast<uint32_t>(z)) {  // same zone: 300 s (src/resampling.jl:58-60)
+                    tt += q16(300.0);
+                } else {
+                    const uint2 rw = row_words[dest >> 5];
+                    const uint32_t bit = 1u << (dest & 31u);
+                    const uint32_t cell = (rw.x & bit) ? rw.y + static_cast<uint32_t>(__popc(rw.x & (bit - 1u))) : kNoCell;
+                    list[n * nthr + tid] = make_uint2(cell, w[u] & idmask);
+                    ++n;
+                }
+            }
+            uint32_t cur = 0, k = 0;
+            double mu = 0.0, inv2s2 = 0.0;
+            uint64_t car = 0;
+            auto next_driver = [&]() {
+                const uint2 e = list[cur * nthr + tid];
+                // (no data for the pair: mean 0, std 0 -> sigma 0 -> 1 / 0, exactly what the division gives)
+                const double2 c = (e.x != kNoCell) ? row_cells[e.x] : make_double2(0.0, __builtin_inf());
+                mu = c.x;
+                inv2s2 = c.y;
+                car = tr.cars.global(e.y);
+            };
+            if (n) next_driver();
+            while (__builtin_amdgcn_ballot_w64(cur < n) != 0ull) {
+                if (cur < n) {
+                    double x;
+                    bool done = truncnormal_attempt(tr.seed, car, step, 1u + 2u * k, mu, inv2s2, x);
+                    ++k;
+                    if (!done && k == kTruncnormalAttempts) {
+                        done = true;
+                        x = mu;
+                    }
+                    if (done) {
+                        tt += q16(x);
+                        ++cur;
+                        k = 0;
+                        if (cur < n) next_driver();
+                    }
+                }
+            }
+        }
+    } else {
     // Batches of kTravelBatch drivers per thread: their run entries, then their two datamatrix cells, are requested together
     // (a driver's chain entry -> cell -> mean, std -> draws is otherwise three exposed round trips).
     constexpr int kTravelBatch = 4;
-    const double2 *tt_row = SPARSE ? nullptr : tr.tt + (static_cast<size_t>(hour) * Z + z) * Z;
+    const double2 *tt_row = tr.tt + (static_cast<size_t>(hour) * Z + z) * Z;
     for (uint32_t i0 = tid; i0 < total; i0 += kTravelBatch * blockDim.x) {
         uint32_t w[kTravelBatch], dest[kTravelBatch];
         bool live[kTravelBatch];
@@ -1719,15 +1796,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
         for (int u = 0; u < kTravelBatch; ++u) {
             const bool moving = live[u] && dest[u] != static_cast<uint32_t>(z);
             double2 cell = make_double2(0.0, 0.0);
-            if constexpr (SPARSE) {
-                if (moving) {
-                    const uint2 w = row_words[dest[u] >> 5];
-                    const uint32_t bit = 1u << (dest[u] & 31u);
-                    if (w.x & bit) cell = row_cells[w.y + static_cast<uint32_t>(__popc(w.x & (bit - 1u)))];
-                }
-            } else {
-                if (moving) cell = tt_row[dest[u]];
-            }
+            if (moving) cell = tt_row[dest[u]];
             mean[u] = cell.x;
             sd[u] = cell.y;
         }
@@ -1741,6 +1810,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
                 tt += q16(truncnormal_pm10(tr.seed, tr.cars.global(w[u] & idmask), step, 1, mean[u], s1));
             }
         }
+    }
     }
     // one global atomic per block, spread over kTravelParts words (atomics on ONE word are served one at a time at the memory
     // side: four per block on the sum itself made this kernel 119 us per hour); k_grouped_travel_finish adds the parts up
@@ -2244,7 +2314,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.cars = cars;
             tr.seed = seed;
             prof_begin(CPM_PROFILE_TRAVEL);
-            if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), tb.tts_lds, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
+            tr.list_off = static_cast<uint32_t>(tb.tts_lds);
+            if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), travel_lds_bytes(tb.tts_lds, travel_block(mean, w.parts > 1)), stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             else launch(k_grouped_travel<false>, dim3(Z, 1), dim3(travel_block(mean, w.parts > 1)), 0, stream, a.D, a.cntg, Z, w.scap, w.idbits, tr);
             prof_end(CPM_PROFILE_TRAVEL);
         }
@@ -2266,7 +2337,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         tr.cars = cars;
         tr.seed = seed;
         prof_begin(CPM_PROFILE_TRAVEL);
-        if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), tb.tts_lds, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
+        tr.list_off = static_cast<uint32_t>(tb.tts_lds);
+        if (tb.tts_words) launch(k_grouped_travel<true>, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), travel_lds_bytes(tb.tts_lds, travel_block(mean, w.parts > 1)), stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
         else launch(k_grouped_travel<false>, dim3(Z, T), dim3(travel_block(mean, w.parts > 1)), 0, stream, w.Dq, w.cntg, Z, w.scap, w.idbits, tr);
         prof_end(CPM_PROFILE_TRAVEL);
     }

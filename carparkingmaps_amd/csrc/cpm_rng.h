@@ -130,34 +130,45 @@ __device__ __forceinline__ double exp_neg(double y)
 // 1e-16), so the decision is the one the full evaluation would take, bit for bit (the oracle always evaluates exp_neg: results are
 // compared exactly in tests/).  On the path y <= 0.5 (the window is +-0.1 mu, sigma >= 0.1 mu) and the undecided band is y^3/6 wide:
 // a wave needs exp_neg -- sixty f64 operations, half of the travel kernel's arithmetic -- for a few per cent of its attempts.
+// One attempt (Philox stream `stream`) for the window of mean mu and inv2s2 = 1 / (2 sigma^2): the proposal in x, true = accepted.
+// Wave-level inside (the ballot): call it where the lanes that are still drawing are the active ones.
+__device__ __forceinline__ bool truncnormal_attempt(uint64_t seed, uint64_t car, uint32_t step, uint32_t stream, double mu, double inv2s2, double &x)
+{
+    const double lo = 0.9 * mu, hi = 1.1 * mu;
+    const double w = hi - lo;
+    double u1, u2;
+    car_uniforms(seed, car, step, stream, u1, u2);
+    x = lo + w * u1;
+    const double d = x - mu;
+    const double y = (d * d) * inv2s2;
+    bool decided = false, accept = false;
+    if (y <= 1.0) {  // (false for NaN; y >= 0 otherwise)
+        const double h = 0.5 * (y * y);
+        const double upper = (1.0 - y) + h;
+        const double lower = upper - (h * y) * (1.0 / 3.0);
+        if (u2 <= lower - 0x1.0p-45) {
+            decided = true;
+            accept = true;
+        } else if (u2 > upper + 0x1.0p-45) {
+            decided = true;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(!decided) != 0ull) {  // (wave-uniform: most waves skip the evaluation altogether)
+        if (!decided) accept = u2 <= exp_neg(y);
+    }
+    return accept;
+}
+constexpr uint32_t kTruncnormalAttempts = 4096;  // then mu
+
+__device__ __forceinline__ double truncnormal_inv2s2(double sigma) { return 1.0 / (2.0 * sigma * sigma); }
+
 __device__ __forceinline__ double truncnormal_pm10(uint64_t seed, uint64_t car, uint32_t step,
                                                    uint32_t stream0, double mu, double sigma)
 {
-    double lo = 0.9 * mu, hi = 1.1 * mu;
-    double w = hi - lo;
-    double inv2s2 = 1.0 / (2.0 * sigma * sigma);
-    for (uint32_t k = 0; k < 4096; ++k) {
-        double u1, u2;
-        car_uniforms(seed, car, step, stream0 + 2 * k, u1, u2);
-        double x = lo + w * u1;
-        double d = x - mu;
-        const double y = (d * d) * inv2s2;
-        bool decided = false, accept = false;
-        if (y <= 1.0) {  // (false for NaN; y >= 0 otherwise)
-            const double h = 0.5 * (y * y);
-            const double upper = (1.0 - y) + h;
-            const double lower = upper - (h * y) * (1.0 / 3.0);
-            if (u2 <= lower - 0x1.0p-45) {
-                decided = true;
-                accept = true;
-            } else if (u2 > upper + 0x1.0p-45) {
-                decided = true;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(!decided) != 0ull) {  // (wave-uniform: most waves skip the evaluation altogether)
-            if (!decided) accept = u2 <= exp_neg(y);
-        }
-        if (accept) return x;
+    const double inv2s2 = truncnormal_inv2s2(sigma);
+    for (uint32_t k = 0; k < kTruncnormalAttempts; ++k) {
+        double x;
+        if (truncnormal_attempt(seed, car, step, stream0 + 2 * k, mu, inv2s2, x)) return x;
     }
     return mu;
 }
