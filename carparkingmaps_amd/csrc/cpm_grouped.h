@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <string>
 
 #include "../../include/cpm.h"
@@ -1155,7 +1156,77 @@ struct PlaceLds {
     uint32_t bins[ZPG], tbins[ZPG], delta[ZPG];
     uint32_t wsum[PB / 64], total;
     uint32_t lstart[KRUNS * (PB / 16) + 1], any_long, go;
+    using zone_t = typename std::conditional<(ZPG <= 256), uint8_t, uint16_t>::type;  // a zone inside its group, in the sorted list
 };
+
+// Runs longer than the 32 entries their lanes hold (rare on flat tables: a few blocks in a thousand) are handled OUT OF LINE, in
+// functions the common path calls behind a short conditional jump.  Inlined, the two pieces sat in the middle of every block's
+// dependency chain as branches over a few hundred instructions, and a placing block lost ~1.5 k cycles at each of the two (3.2 k +
+// 1.5 k of its 11.8 k-cycle life, tools/hour_stamps.py with finer stamps; with the pieces compiled out both vanished) -- whether the
+// jump was taken over the block or fell through in front of it: the far end of a branch costs an instruction fetch from memory.
+// surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+__device__ __forceinline__ uint32_t place_surplus_entry(const PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t e)
+{
+    constexpr int kRuns = (KRUNS / 2) * (PB / 8);
+    int r = 0;
+    constexpr int kTop = kRuns <= 64 ? 32 : kRuns <= 128 ? 64 : kRuns <= 256 ? 128 : 256;  // (kRuns need not be a power of two)
+#pragma unroll
+    for (int step = kTop; step > 0; step >>= 1)
+        if (r + step < kRuns && pl.lstart[r + step] <= e) r += step;
+    const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + r)
+    return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - pl.lstart[r])]);
+}
+// exclusive scan of the surplus lengths (one per thread), then the histogram of the surplus entries (tbins); returns their number
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+__device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits)
+{
+    constexpr int kRuns = (KRUNS / 2) * (PB / 8), kSurplusBatch = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t len = tid < kRuns ? pl.lstart[tid] : 0u;
+    const uint32_t incl = wave_incl_scan(len);
+    if (lane == 63) pl.wsum[wave] = incl;
+    lds_barrier();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += pl.wsum[w];
+    if (tid < kRuns) pl.lstart[tid] = before + incl - len;
+    if (tid == kRuns - 1) pl.lstart[kRuns] = before + incl;
+    lds_barrier();
+    const uint32_t ltotal = pl.lstart[kRuns];
+    for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * PB) {  // (a thread's kSurplusBatch loads are in flight together)
+        uint32_t w[kSurplusBatch];
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u)
+            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u)
+            if (e0 + u * PB < ltotal) atomicAdd(&pl.tbins[w[u] >> idbits], 1u);
+    }
+    lds_barrier();
+    return ltotal;
+}
+// the surplus entries straight to their buckets (tbins: the running position inside each bucket)
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+__device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits,
+                                               int zg0, uint32_t cap, uint32_t *__restrict__ ids_next, uint32_t ltotal)
+{
+    constexpr int kSurplusBatch = 4;
+    const int tid = threadIdx.x;
+    const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
+    for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * PB) {
+        uint32_t w[kSurplusBatch];
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u)
+            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
+#pragma unroll
+        for (int u = 0; u < kSurplusBatch; ++u)
+            if (e0 + u * PB < ltotal) {
+                const uint32_t dl = w[u] >> idbits;
+                const uint32_t p = atomicAdd(&pl.tbins[dl], 1u);
+                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
+            }
+    }
+}
 
 // FUSED: the block's input is written by sampler workgroups of the SAME launch (those of chunk j of origin zones: lower block
 // indices, dispatched before it).  One wave polls the chunk's counter (relaxed agent-scope loads, s_sleep between them) until all
@@ -1172,16 +1243,22 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     // A run's first 32 entries are held by EIGHT lanes, four consecutive entries each: one 16-byte load per lane and run (two 4-byte
     // loads per lane with sixteen lanes per run before: 12 load instructions per thread instead of 4, and in the fused hour, where
     // the runs are read past this CU's L1 (sc1), a fabric request per dword instead of one per 16 bytes).
-    static_assert(KDEEP == 2 && KRUNS % 2 == 0, "written for 32 register entries per run");
+    // KDEEP = 4: a SECOND 16-byte load per lane and run (entries 32 .. 63), requested with the first whatever the run's length turns
+    // out to be.  A run of more than 32 entries is no exception at S4k (~500 drivers of a zone over 32 groups: 16 on average, 28 where
+    // p_drive is 0.9): most blocks take the long-run path (place_surplus_*: a scan over the block's runs between two barriers, then
+    // dependent loads, twice -- 5 k cycles of a placing block's 12.5 k in the fused hour, tools/hour_stamps.py).  With 64 entries in
+    // registers the block's chain is then bound by the ticket's round trip instead, and the hour does not move (kFusedKdeep).
+    static_assert((KDEEP == 2 || KDEEP == 4) && KRUNS % 2 == 0, "written for 32 or 64 register entries per run");
     constexpr int kPlaceBlock = PB, kPlaceSeg = PB / 8;    // 8-lane segments: one run each per pass
     constexpr int KR = KRUNS / 2;                          // runs per lane segment (= passes)
+    constexpr int kQ = KDEEP / 2, kE = 4 * kQ;             // 16-byte loads / entries per lane and run
     constexpr int kSlots = KRUNS * KDEEP * kPlaceBlock;    // entries a block can hold in registers
     constexpr int kRuns = KR * kPlaceSeg;
-    constexpr int kSurplusBatch = 4;
     uint32_t(&bins)[ZPG] = pl.bins, (&tbins)[ZPG] = pl.tbins, (&delta)[ZPG] = pl.delta;
     uint32_t(&wsum)[PB / 64] = pl.wsum, &s_total = pl.total;
     uint32_t(&lstart)[kRuns + 1] = pl.lstart, &s_any_long = pl.any_long;
-    uint16_t *sorted_zone = reinterpret_cast<uint16_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
+    using zone_t = typename PlaceLds<PB, KRUNS, ZPG>::zone_t;
+    zone_t *sorted_zone = reinterpret_cast<zone_t *>(sorted_ids + kSlots);  // [kSlots] their zone inside the group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int zg0 = g * zpg;
     const int nzl = max(0, min(zpg, Z - zg0));
@@ -1219,7 +1296,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
             return;
         }
     }
-    uint32_t c[KR], v[KR][4], r[KR][4];
+    uint32_t c[KR], v[KR][kE], r[KR][kE];
     // (the block's runs behind one buffer descriptor: zone zs0's group-0 run is byte 0; < 2^32 bytes for every region size)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(D) + static_cast<size_t>(zs0) * kGroups * scap, 0,
@@ -1229,12 +1306,15 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
         const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
         c[k] = hand_load<FUSED>(&cntg[run]);
-        const cpm_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(zc - zs0) * kGroups + g) * scap + 4u * l8) << 2, 0,
-                                                                  FUSED ? 16 : 0);  // (aux 16: sc1)  scap >= 32; beyond c[k]: stale, masked
-        v[k][0] = q.x;
-        v[k][1] = q.y;
-        v[k][2] = q.z;
-        v[k][3] = q.w;
+#pragma unroll
+        for (int h = 0; h < kQ; ++h) {  // (entries 32 h + 4 l8 ... of the run)
+            const cpm_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(zc - zs0) * kGroups + g) * scap + 32u * h + 4u * l8) << 2, 0,
+                                                                      FUSED ? 16 : 0);  // (aux 16: sc1)  scap >= 64; beyond c[k]: stale, masked
+            v[k][4 * h + 0] = q.x;
+            v[k][4 * h + 1] = q.y;
+            v[k][4 * h + 2] = q.z;
+            v[k][4 * h + 3] = q.w;
+        }
     }
     lds_barrier();
     CPM_PSTAMP(1);
@@ -1247,9 +1327,9 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < kE; ++d) {
             r[k][d] = 0;
-            if (static_cast<uint32_t>(4 * l8 + d) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
+            if (static_cast<uint32_t>(32 * (d / 4) + 4 * l8 + (d % 4)) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
         }
     }
     if (l8 == 0) {
@@ -1263,40 +1343,9 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     CPM_PSTAMP(2);
     lds_barrier();
     CPM_PSTAMP(3);
-    // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
-    auto surplus_entry = [&](uint32_t e) -> uint32_t {
-        int r = 0;
-        constexpr int kTop = kRuns <= 64 ? 32 : kRuns <= 128 ? 64 : kRuns <= 256 ? 128 : 256;  // largest power of two < kRuns ... (kRuns need not be one)
-#pragma unroll
-        for (int step = kTop; step > 0; step >>= 1)
-            if (r + step < kRuns && lstart[r + step] <= e) r += step;
-        const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + (r % kPlaceSeg) + (r / kPlaceSeg) * kPlaceSeg = zs0 + r)
-        return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - lstart[r])]);
-    };
-    const bool any_long = s_any_long != 0;  // (block-uniform)
+    const bool any_long = __builtin_amdgcn_readfirstlane(static_cast<int>(s_any_long)) != 0;  // (block-uniform, in a scalar register)
     uint32_t ltotal = 0;
-    if (any_long) {
-        // exclusive scan of the surplus lengths (kRuns <= kPlaceBlock values, one per thread), then the histogram of the surplus
-        const uint32_t len = tid < kRuns ? lstart[tid] : 0u;
-        const uint32_t incl = wave_incl_scan(len);
-        if (lane == 63) wsum[wave] = incl;
-        lds_barrier();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (tid < kRuns) lstart[tid] = before + incl - len;
-        if (tid == kRuns - 1) lstart[kRuns] = before + incl;
-        lds_barrier();
-        ltotal = lstart[kRuns];
-        for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {  // (a thread's kSurplusBatch loads are in flight together)
-            uint32_t w[kSurplusBatch];
-#pragma unroll
-            for (int u = 0; u < kSurplusBatch; ++u) w[u] = (e0 + u * kPlaceBlock < ltotal) ? surplus_entry(e0 + u * kPlaceBlock) : 0u;
-#pragma unroll
-            for (int u = 0; u < kSurplusBatch; ++u)
-                if (e0 + u * kPlaceBlock < ltotal) atomicAdd(&tbins[w[u] >> idbits], 1u);
-        }
-        lds_barrier();
-    }
+    if (any_long) ltotal = place_surplus_count<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, idbits);
     // The ticket (this block's range inside each bucket of the group) is requested now and needed only when the sorted list is
     // written out: its round trip runs under the block scan of the histogram (the zones' offsets in the sorted list) and the sort.
     const bool zone = tid < nzl;
@@ -1321,12 +1370,12 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-            if (static_cast<uint32_t>(4 * l8 + d) < c[k]) {
+        for (int d = 0; d < kE; ++d)
+            if (static_cast<uint32_t>(32 * (d / 4) + 4 * l8 + (d % 4)) < c[k]) {
                 const uint32_t dl = v[k][d] >> idbits;
                 const uint32_t li = bins[dl] + r[k][d];
                 sorted_ids[li] = v[k][d] & idmask;
-                sorted_zone[li] = static_cast<uint16_t>(dl);
+                sorted_zone[li] = static_cast<zone_t>(dl);
             }
     }
     if (zone) {  // (first use of the ticket)
@@ -1354,18 +1403,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
-    for (uint32_t e0 = tid; e0 < ltotal; e0 += kSurplusBatch * kPlaceBlock) {
-        uint32_t w[kSurplusBatch];
-#pragma unroll
-        for (int u = 0; u < kSurplusBatch; ++u) w[u] = (e0 + u * kPlaceBlock < ltotal) ? surplus_entry(e0 + u * kPlaceBlock) : 0u;
-#pragma unroll
-        for (int u = 0; u < kSurplusBatch; ++u)
-            if (e0 + u * kPlaceBlock < ltotal) {
-                const uint32_t dl = w[u] >> idbits;
-                const uint32_t p = atomicAdd(&tbins[dl], 1u);
-                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
-            }
-    }
+    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, idbits, zg0, cap, ids_next, ltotal);
     CPM_PSTAMP(7);
 #if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER) && !defined(CPM_STAMP_BOTH)
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
@@ -1409,6 +1447,13 @@ __global__ __launch_bounds__(PB) void k_grouped_place(const uint32_t *__restrict
 #define CPM_FUSED_KRUNS 4
 #endif
 constexpr int kFusedKruns = CPM_FUSED_KRUNS;
+#ifndef CPM_FUSED_KDEEP
+#define CPM_FUSED_KDEEP 2
+#endif
+// 2: 32 entries of a run in registers, 4: 64 (a second 16-byte load per lane).  MEASURED (S4k, one box, interleaved runs): 4 takes the
+// long-run path out of most blocks' chains (a placing block lives 11.6 k cycles instead of 12.5 k) and the hour is the same to 0.1 %
+// (0.8849 against 0.8861 ms per resample) for 128 B more read per run: 2 it stays.
+constexpr int kFusedKdeep = CPM_FUSED_KDEEP;
 constexpr int kFusedChunk = 16 * kFusedKruns;  // origin zones per chunk = runs a 256-thread placing block takes (8 lanes per run, KRUNS / 2 passes)
 constexpr int kDoneStride = 32;  // words between the hand-off counters of consecutive chunks: a 128-B line each (64 adds and the polls of 32
                                  // placing blocks per counter; with all of an hour's counters in two lines every add and every poll of the
@@ -1458,7 +1503,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
 #ifdef CPM_PLACE_PRIO
         __builtin_amdgcn_s_setprio(CPM_PLACE_PRIO);
 #endif
-        grouped_place_body<kFusedThreads, kFusedKruns, 2, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
+        grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
                                                                   a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride,
                                                                   need, a.spin_limit);
     }
@@ -1870,7 +1915,7 @@ inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2
 // the fused hour (k_grouped_hour): (chunks + lag) x (kFusedChunk sampler workgroups + kGroups placing blocks)
 inline size_t fused_lds_bytes(int Zq, int G)
 {
-    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(6) * kFusedKruns * 2 * kFusedThreads);
+    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(4 + sizeof(PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg>::zone_t)) * kFusedKruns * kFusedKdeep * kFusedThreads);
 }
 template <int CPT, int NQ>
 inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
