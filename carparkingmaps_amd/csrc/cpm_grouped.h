@@ -200,6 +200,10 @@ struct GroupedArgs {
     int lag;                  // fused hour: the placing blocks of chunk j sit behind the sampler workgroups of chunk j + lag
     uint32_t heavy_x;         // a bucket is heavy above heavy_x x the slots of its sampler workgroup (kHeavy; less once the heavy launch runs anyway)
     uint32_t spin_limit;      // fused hour: polls a placing block makes before it gives up (0: at once -- the tests' way into the bail-out)
+    // placing first (k_grouped_hour_pf): the runs of the PREVIOUS hour, which this launch's placing blocks move into THIS hour's buckets
+    // (ids / cnt_a above) before its sampler workgroups read them; pchunks = chunks of origin zones to place (0: nothing pending)
+    const uint32_t *pD, *pcntg;
+    int pchunks;
     uint32_t cap, scap, idbits, gshift, step;
     // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
     //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
@@ -217,6 +221,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Votes on a condition that already is a lane mask: HIP's __ballot / __any take an int, and hipcc materialises the mask as 0 / 1 in
 // a VGPR and compares it again (two VALU instructions per vote; the sampler is bound by what it issues).
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15u; }
 // Inclusive prefix sum over the 64 lanes of a wave in the vector ALU (DPP: shifts inside a row of 16 lanes, then the last lane of
 // a row broadcast to the rows behind it): six dependent additions and no LDS instruction.  __shfl_up is a ds_bpermute per step --
 // a round trip through the LDS pipeline, which the sampler workgroups sharing the CU keep busy: the placing blocks' scan of their
@@ -768,8 +774,15 @@ __device__ __forceinline__ void hand_off_done(uint32_t *done_chunk, int tid)
     }
 }
 
-template <int BLOCK, int CPT, int NQ, bool GROUPED, bool FUSED>
-__device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const int z, uint32_t *pack, SampleLds &sl, uint32_t *done_chunk)
+// WAIT (placing first, k_grouped_hour_pf): the arrivals of this hour's buckets are written by placing blocks of the SAME launch
+// (lower block indices).  A wave asks for the counter of its zone's destination group FIRST, then for the pack (LDS-DMA): with
+// vmcnt <= NQ the counter is in its register while the pack is still landing.  Only when every placing block of the group has counted
+// itself in (its stores drained) are the arrival count and the ids read -- past the L2 (sc1), as the placing blocks wrote them.
+// Slot s of the workgroup: stayer s below the stayers' count, else arrival s - ns from the TOP of the region -- a position that
+// does not depend on the arrivals' count, so count and ids are requested together.
+template <int BLOCK, int CPT, int NQ, bool GROUPED, bool FUSED, bool WAIT = false>
+__device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const int z, uint32_t *pack, SampleLds &sl, uint32_t *done_chunk,
+                                                    const uint32_t *wait_on = nullptr, uint32_t wait_need = 0)
 {
     uint32_t &s_ndrive = sl.ndrive, &s_nstay = sl.nstay, &s_split = sl.split;
     uint32_t(&gb)[kGroups] = sl.gb;
@@ -785,24 +798,63 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     // means the ids are in their registers.
     CPM_SSTAMP_DECL;
     CPM_SSTAMP(0);
-    const uint32_t ns_raw = a.cnt_s[z], na_raw = a.cnt_a[z];
+    const uint32_t ns_raw = a.cnt_s[z];
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
+    uint32_t na_raw;
+    uint32_t id[CPT + 1];
+    if constexpr (WAIT) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 seen = {wait_need, 0u};  // {placing blocks of the group that have counted themselves in, the XCDs they ran on}
+        if (wait_need) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(seen) : "v"(0), "s"(wait_on) : "memory");
+        pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
+        if (wait_need) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen) : "n"(NQ) : "memory");
+            uint32_t got = from_lane0(seen.x), where = from_lane0(seen.y);
+            for (uint32_t spins = 0; got < wait_need; ++spins) {  // (rare: the placing blocks come first in the launch)
+                if (spins >= a.spin_limit) break;  // bounded: the step is then invalid, the context repeats it with two launches per hour
+                __builtin_amdgcn_s_sleep(32);
+                got = from_lane0(lane == 0 ? __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+                where = from_lane0(lane == 0 ? __hip_atomic_load(wait_on + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+            }
+            // (the mask is complete once the count is: a block ORs its XCD in before it counts itself in)
+            if ((got < wait_need || where != (1u << xcc_id())) && lane == 0) atomicOr(a.rare->status, 4ull);
+        }
+        const uint32_t nsc = min(ns_raw, cap);
+        uint32_t nav;
+        asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(nav) : "v"(0), "s"(a.cnt_a + z) : "memory");
+#pragma unroll
+        for (int c = 0; c <= CPT; ++c) {
+            const uint32_t s1 = static_cast<uint32_t>(tid + c * BLOCK);
+            const uint32_t pos = s1 < nsc ? s1 : (cap - 1u + nsc - min(s1, cap - 1u + nsc));
+            asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(id[c]) : "v"(pos << 2), "s"(a.ids + b) : "memory");
+        }
+        if constexpr (CPT == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4])::"memory");
+        else if constexpr (CPT == 2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1])::"memory");
+        na_raw = from_lane0(nav);
+    } else {
+        na_raw = a.cnt_a[z];
+    }
     // the bucket: stayers in slots [0, ns) of the region, arrivals in its last na slots; slot s of the workgroup reads position
     // s + (s >= ns ? gap : 0), gap = cap - ns - na (clamped to the region: slots beyond ns + na hold no car)
     const uint32_t ns = min(ns_raw, cap), na = min(na_raw, cap - ns);
     const uint32_t n_all = ns + na;
-    const uint32_t ns4 = ns << 2, gap4 = (cap - n_all) << 2, top4 = (cap - 1) << 2;
-    uint32_t id[CPT + 1];
+    if constexpr (!WAIT) {
+        const uint32_t ns4 = ns << 2, gap4 = (cap - n_all) << 2, top4 = (cap - 1) << 2;
 #pragma unroll
-    for (int c = 0; c <= CPT; ++c) {
-        // (the bucket's base in scalar registers + a 32-bit byte offset: cap x 4 B < 2^32)
-        const uint32_t s4 = static_cast<uint32_t>(tid + c * BLOCK) << 2;
-        const uint32_t off = min(s4 + (s4 >= ns4 ? gap4 : 0u), top4);
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(id[c]) : "v"(off), "s"(a.ids + b) : "memory");
+        for (int c = 0; c <= CPT; ++c) {
+            // (the bucket's base in scalar registers + a 32-bit byte offset: cap x 4 B < 2^32)
+            const uint32_t s4 = static_cast<uint32_t>(tid + c * BLOCK) << 2;
+            const uint32_t off = min(s4 + (s4 >= ns4 ? gap4 : 0u), top4);
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(id[c]) : "v"(off), "s"(a.ids + b) : "memory");
+        }
+        pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
+        wait_ids<CPT + 1, NQ>(id);
     }
-    pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
-    wait_ids<CPT + 1, NQ>(id);
     CPM_SSTAMP(1);
     // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
     // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
@@ -922,7 +974,9 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         if (q0 + static_cast<uint32_t>(tid & ~63) >= n) continue;  // none of this wave's 64 slots holds a car (no barrier inside the loop)
         const uint32_t q = q0 + tid;
         const bool valid1 = q < n;
-        const uint32_t idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q + (q >= ns ? cap - n_all : 0u)] : 0u);
+        uint32_t idx;
+        if constexpr (WAIT) idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? hand_load<true>(&a.ids[b + (q < ns ? q : cap - 1u + ns - q)]) : 0u);
+        else idx = (q0 == CPT * BLOCK) ? id[CPT] : (valid1 ? a.ids[b + q + (q >= ns ? cap - n_all : 0u)] : 0u);
         const uint64_t car = a.cars.global(idx);
         long long kb;
         uint32_t clo1[1], khi1[1], dest1[1];
@@ -992,7 +1046,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     }
     CPM_SSTAMP(7);
 #ifdef CPM_STAMP_BOTH
-    if constexpr (FUSED)  // (only the fused hour's blocks: the buffer then holds the last fused launch of the resample)
+    if constexpr (FUSED || WAIT)  // (only the fused hour's blocks: the buffer then holds the last fused launch of the resample)
 #endif
     CPM_SSTAMP_FLUSH;
     hand_off_done<FUSED>(done_chunk, tid);
@@ -1206,7 +1260,7 @@ __device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &p
     return ltotal;
 }
 // the surplus entries straight to their buckets (tbins: the running position inside each bucket)
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL>
 __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits,
                                                int zg0, uint32_t cap, uint32_t *__restrict__ ids_next, uint32_t ltotal)
 {
@@ -1234,11 +1288,14 @@ __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, con
 // leaves -- the step is then invalid and the context repeats it with two launches per hour (a placement or dispatch order this
 // protocol did not expect can cost time, never a hang).  The runs are then read with sc1 loads (hand_load).
 constexpr uint32_t kFusedSpinLimit = 1u << 15;  // default number of polls: x (one L2 round trip + s_sleep 32) = tens of milliseconds
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+// SIGNAL (placing first, k_grouped_hour_pf): the buckets this block fills are read by sampler workgroups of the SAME launch -- the
+// ids are stored write-through (sc1), and when the block is done every wave drains its stores, the block meets and one lane counts
+// the block in on its destination group's counter (done_out), which the group's sampler workgroups ask for before they read.
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL = false>
 __device__ __forceinline__ void grouped_place_body(const int g, const int j, PlaceLds<PB, KRUNS, ZPG> &pl, uint32_t *sorted_ids, const uint32_t *__restrict__ D,
                                                    const uint32_t *__restrict__ cntg, int zpg, int zps, int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
                                                    uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next, unsigned long long *status,
-                                                   const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit)
+                                                   const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit, uint32_t *done_out = nullptr)
 {
     // A run's first 32 entries are held by EIGHT lanes, four consecutive entries each: one 16-byte load per lane and run (two 4-byte
     // loads per lane with sixteen lanes per run before: 12 load instructions per thread instead of 4, and in the fused hour, where
@@ -1403,12 +1460,23 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
-    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, idbits, zg0, cap, ids_next, ltotal);
+    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL>(pl, D, g, zs0, zs1, scap, idbits, zg0, cap, ids_next, ltotal);
     CPM_PSTAMP(7);
 #if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER) && !defined(CPM_STAMP_BOTH)
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
 #endif
     CPM_PSTAMP_FLUSH;
+    if constexpr (SIGNAL) {
+        // the ids were stored plainly: they lie in THIS XCD's L2 (all writes to a bucket merge there), which is where a sampler
+        // workgroup of the same XCD reads them (sc1 loads are served by the L2).  The block leaves its XCD's number beside the counter;
+        // a sampler workgroup that finds another XCD's there than its own gives the step up (status bit 2).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            __hip_atomic_fetch_or(done_out + 1, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(done_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int PB, int KRUNS, int KDEEP>
@@ -1506,6 +1574,41 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
                                                                   a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride,
                                                                   need, a.spin_limit);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the hour, placing first
+// ONE launch per hour the other way round: the placing blocks that move the PREVIOUS hour's drivers into this hour's buckets,
+// then this hour's sampler workgroups.  At the head of a launch every placing block has its input complete (the runs were written
+// by the previous launch) and all of them start at once, whereas behind the samplers of their own hour (k_grouped_hour) they
+// trickle in as chunks complete and queue for the block slots the last samplers free: there the hour ends with ~1.6 placing-block
+// lifetimes in which the vector units idle (tools/hour_stamps.py), here it begins with one.  A sampler workgroup waits for the
+// placing blocks of ITS zone's destination group only (grouped_sample_body<WAIT>); blocks are laid out 8 groups at a time --
+// block = (g / 8) * 8 * chunks + j * 8 + g % 8 -- so the groups of the first sets are complete while later sets still run (and the
+// blocks of one group share blockIdx % 8 = one XCD).  A block only ever waits for blocks of LOWER index, which never wait themselves.
+// GROUPED = false: the last hour of a resample (sampled, never applied) behind the placing of the hour before it.
+template <int CPT, int NQ, bool GROUPED>
+__global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_hour_pf(GroupedArgs a)
+{
+    extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
+    __shared__ union {
+        SampleLds s;
+        PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg> p;
+    } u;
+    const int npl = a.pchunks * kGroups;  // (a multiple of 8)
+    if (static_cast<int>(blockIdx.x) < npl) {
+        const int b = blockIdx.x;
+        const int g = (b / (8 * a.pchunks)) * 8 + (b & 7), j = (b >> 3) % a.pchunks;
+        grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, false, true>(
+            g, j, u.p, dyn, a.pD, a.pcntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits, const_cast<uint32_t *>(a.cnt_a),
+            const_cast<uint32_t *>(a.ids), a.rare->status, nullptr, 0u, 0u, a.done_t + static_cast<size_t>(g) * kDoneStride);
+    } else {
+        // sampler block 8 q + x takes a zone of a group g with g % 8 == x: the XCD its arrivals were placed on (blockIdx % 8)
+        const int bs = blockIdx.x - npl, zpg = 1 << a.gshift;
+        const int g = (bs & 7) + 8 * ((bs >> 3) / zpg), z = g * zpg + ((bs >> 3) % zpg);
+        if (g >= kGroups || z >= a.Z) return;
+        grouped_sample_body<kFusedThreads, CPT, NQ, GROUPED, false, true>(a, z, dyn, u.s, nullptr, a.done_t + static_cast<size_t>(g) * kDoneStride,
+                                                                          static_cast<uint32_t>(a.pchunks));
     }
 }
 
@@ -1963,6 +2066,44 @@ inline void grouped_launch_hour(const GroupedArgs &a, int64_t mean, hipStream_t 
     }
 }
 
+template <int CPT, int NQ, bool GROUPED>
+inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
+{
+    const size_t lds = fused_lds_bytes(a.Zq, a.G);
+    if (lds > 48 * 1024) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour_pf<CPT, NQ, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    launch(k_grouped_hour_pf<CPT, NQ, GROUPED>, dim3(static_cast<unsigned>(a.pchunks * kGroups + (kGroups << a.gshift))), dim3(kFusedThreads), lds, stream, a);
+}
+template <int CPT, bool GROUPED>
+inline void grouped_launch_hour_pf_c(const GroupedArgs &a, hipStream_t stream)
+{
+    const int need = (pack_row_words(a.Zq, a.G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (need <= 1) grouped_launch_hour_pf_nq<CPT, 1, GROUPED>(a, stream);
+    else if (need <= 2) grouped_launch_hour_pf_nq<CPT, 2, GROUPED>(a, stream);
+    else if (need <= 3) grouped_launch_hour_pf_nq<CPT, 3, GROUPED>(a, stream);
+    else if (need <= 4) grouped_launch_hour_pf_nq<CPT, 4, GROUPED>(a, stream);
+    else if (need <= 5) grouped_launch_hour_pf_nq<CPT, 5, GROUPED>(a, stream);
+    else if (need <= 6) grouped_launch_hour_pf_nq<CPT, 6, GROUPED>(a, stream);
+    else if (need <= 8) grouped_launch_hour_pf_nq<CPT, 8, GROUPED>(a, stream);
+    else grouped_launch_hour_pf_nq<CPT, 12, GROUPED>(a, stream);
+}
+template <bool GROUPED>
+inline void grouped_launch_hour_pf(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+{
+    switch (grouped_cpt(mean)) {
+    case 1: grouped_launch_hour_pf_c<1, GROUPED>(a, stream); break;
+    case 2: grouped_launch_hour_pf_c<2, GROUPED>(a, stream); break;
+    default: grouped_launch_hour_pf_c<4, GROUPED>(a, stream); break;
+    }
+}
+
 template <int CPT, int NQ>
 inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, size_t lds, hipStream_t stream)
 {
@@ -2081,7 +2222,7 @@ inline bool grouped_path_fits(int64_t n, int Z, int cap_mult = 4)
     const uint32_t cap = grouped_cap(n, Z, cap_mult);
     if (n > (int64_t(1) << grouped_idbits(Z)) || (1 << grouped_gshift(Z)) > kMaxZonesPerGroup) return false;
     if (!place_shape_fits(Z)) return false;
-    const int64_t bytes = static_cast<int64_t>(Z) * cap * 4 * 3 + static_cast<int64_t>(Z) * kGroups * grouped_scap(cap) * 4;
+    const int64_t bytes = static_cast<int64_t>(Z) * cap * 4 * 3 + 2 * static_cast<int64_t>(Z) * kGroups * grouped_scap(cap) * 4;
     return bytes <= (int64_t(cap_mult <= 4 ? 24 : 80) << 30);
 }
 
@@ -2099,6 +2240,7 @@ struct GroupedWork {
     uint32_t heavy_x_seen = 2;                                   // the heavy threshold (x a workgroup's slots) once heavy buckets were seen: the heavy launch runs
                                                                  // anyway then, and a bucket of 2-4 x the slots walked by ONE workgroup is the sampler's tail
     bool fused_ok = true;                                        // the fused hour is used (CPM_OPT_FUSED; cleared for good when a placing block gave up waiting)
+    bool fused_pf = false;                                       // ... in its placing-first form (k_grouped_hour_pf): the previous hour's placing blocks, then the samplers
     int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
                                                                  // every sampler workgroup first, then every placing block
     uint32_t fused_spin = kFusedSpinLimit;
@@ -2108,7 +2250,7 @@ struct GroupedWork {
     GroupedRare *rare = nullptr;                                 // what the rare branches of the hourly kernels read (written by k_grouped_zero per run)
     uint32_t *maxn = nullptr;                                    // [2] of the current run: largest heavy bucket (> kHeavy x the sampler workgroup's slots), most heavy buckets in one hour
     uint32_t *heavy_list = nullptr, *nheavy = nullptr;           // [kHeavyCap] zones handed to the heavy kernel this hour; [T+1] how many, per hour
-    int run_hours = 1;                                           // copies of Dq / cntg: 1, or T when the runs of every hour of a resample are kept (ensure_history)
+    int run_hours = 2;                                           // copies of Dq / cntg: 2 (alternating hours), or T when the runs of every hour of a resample are kept (ensure_history)
     int parts = 1;                                               // workgroups per heavy zone: 1 + blocks of the heavy kernel (set_parts)
     int hgrid = 0;                                               // zones the heavy launch covers
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
@@ -2121,7 +2263,7 @@ struct GroupedWork {
         hgrid = parts > 1 ? static_cast<int>(std::min<int64_t>(kHeavyCap, most_heavy_buckets + most_heavy_buckets / 4 + 32)) : 0;  // (work items)
     }
 
-    size_t fused_chunks() const { return static_cast<size_t>((Z + kFusedChunk - 1) / kFusedChunk); }
+    size_t fused_chunks() const { return static_cast<size_t>(std::max((Z + kFusedChunk - 1) / kFusedChunk, kGroups)); }  // (counter lines per hour: by chunk, or by group)
     size_t done_base() const { return (static_cast<size_t>(T + 1) * 2 * Z + kDoneStride - 1) / kDoneStride * kDoneStride; }  // (whole lines)
     size_t cnt_words() const { return done_base() + static_cast<size_t>(T) * fused_chunks() * kDoneStride; }
     size_t run_words() const { return static_cast<size_t>(Z) * kGroups * scap; }
@@ -2158,7 +2300,7 @@ struct GroupedWork {
         if (rare) (void)hipFree(rare);
         rare = nullptr;
         n = 0;
-        run_hours = 1;
+        run_hours = 2;
         buckets0_valid = false;
     }
 
@@ -2186,8 +2328,9 @@ struct GroupedWork {
         alloc(&idsB, slots);
         alloc(&cnt0, 2 * static_cast<size_t>(Z));
         alloc(&cnt, cnt_words());
-        alloc(&Dq, static_cast<size_t>(Z) * kGroups * scap);
-        alloc(&cntg, static_cast<size_t>(Z) * kGroups);
+        alloc(&Dq, 2 * static_cast<size_t>(Z) * kGroups * scap);  // (two hours: the placing-first hour reads the last hour's runs while this hour's are written)
+        alloc(&cntg, 2 * static_cast<size_t>(Z) * kGroups);
+        run_hours = 2;
         alloc(&heavy_list, kHeavyCap);
         alloc(&nheavy, static_cast<size_t>(T) + 1);
         if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
@@ -2290,6 +2433,15 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     const int64_t mean = (n + Z - 1) / Z;
     const uint32_t *ids = w.ids0, *cnt = w.cnt0;
     const int hours = ivp ? T - 1 : T;
+    // placing first: the drivers of the hour before, still in their runs, wait for the next launch to move them into `ids` / `cnt`
+    const uint32_t *pend_D = nullptr, *pend_cntg = nullptr;
+    auto flush_pending = [&]() {  // ... or for a placing launch of their own, when that launch is not of the placing-first kind
+        if (!pend_D) return;
+        prof_begin(CPM_PROFILE_PLACE);
+        grouped_launch_place(stream, pend_D, pend_cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, const_cast<uint32_t *>(cnt) + Z, const_cast<uint32_t *>(ids), status);
+        prof_end(CPM_PROFILE_PLACE);
+        pend_D = pend_cntg = nullptr;
+    };
     for (int t = 0; t < hours; ++t) {
         const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
         // hour T of a resample is sampled, never applied (src/resampling.jl:81-83): counts only -- unless its travel times are wanted,
@@ -2309,8 +2461,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.hour = t;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
-        a.D = w.Dq + (history ? w.run_words() * t : 0);
-        a.cntg = w.cntg + (history ? w.len_words() * t : 0);
+        a.D = w.Dq + w.run_words() * (history ? t : (t & 1));
+        a.cntg = w.cntg + w.len_words() * (history ? t : (t & 1));
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.Z = Z;
@@ -2324,19 +2476,31 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.cars = cars;
         a.seed = seed;
         // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
-        const bool fuse = grouped && !last_hour && w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G);
+        const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G);
+        const bool pf = shape && w.fused_pf;  // (also the last hour, in its plain form: the placing of the hour before it rides in front)
+        const bool fuse = grouped && !last_hour && shape && !pf;
+        if (!pf) flush_pending();
+        a.pD = pend_D;
+        a.pcntg = pend_cntg;
+        a.pchunks = pend_D ? (Z + kFusedChunk - 1) / kFusedChunk : 0;
+        pend_D = pend_cntg = nullptr;
         a.done_t = w.cnt + w.done_base() + static_cast<size_t>(t) * w.fused_chunks() * kDoneStride;
         a.lag = w.fused_lag;
         a.heavy_x = w.parts > 1 ? w.heavy_x_seen : kHeavy;
         a.spin_limit = w.fused_spin;
         prof_begin(CPM_PROFILE_SAMPLER);
-        if (fuse) grouped_launch_hour(a, mean, stream);
+        if (pf && grouped) grouped_launch_hour_pf<true>(a, mean, stream);
+        else if (pf) grouped_launch_hour_pf<false>(a, mean, stream);
+        else if (fuse) grouped_launch_hour(a, mean, stream);
         else if (grouped) grouped_launch_sample<true>(a, mean, stream);
         else grouped_launch_sample<false>(a, mean, stream);
         prof_end(CPM_PROFILE_SAMPLER);
-        if (grouped && !fuse) grouped_launch_heavy(a, w.parts, w.hgrid, mean, stream);
+        if (grouped && !fuse && !pf) grouped_launch_heavy(a, w.parts, w.hgrid, mean, stream);
         if (!last_hour) {
-            if (!fuse) {
+            if (pf) {
+                pend_D = a.D;
+                pend_cntg = a.cntg;
+            } else if (!fuse) {
                 prof_begin(CPM_PROFILE_PLACE);
                 grouped_launch_place(stream, a.D, a.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next + Z, ids_next, status);
                 prof_end(CPM_PROFILE_PLACE);
@@ -2391,6 +2555,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         hipLaunchKernelGGL(k_grouped_travel_finish, dim3(1), dim3(kTravelParts), 0, stream, w.tt_part, tt_sum);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "travel-time sum");
     }
+    flush_pending();  // (an IVP ends on a placing: its final buckets are read below)
     if (ivp) {
         hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, cnt + Z, w.cap, d_zone0_out, status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");

@@ -63,7 +63,8 @@ class Sampler:
 
     def set_fused(self, mode=1, lag=None):
         """The grouped path's fused hour: 1 on (default), 0 two launches per hour, 2 on with placing blocks that give up at once
-        (tests); lag: chunks of sampler workgroups in front of a chunk's placing blocks."""
+        (tests), 3 the placing-first form (the previous hour's placing blocks in front of the hour's samplers), 4 = 3 with samplers
+        that give up at once (tests); lag: chunks of sampler workgroups in front of a chunk's placing blocks (mode 1)."""
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED, int(mode)))
         if lag is not None:
             _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED_LAG, int(lag)))

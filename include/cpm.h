@@ -69,7 +69,10 @@ extern "C" {
                                    dispatch's own begin and end (hipExtLaunchKernelGGL); 0: off */
 #define CPM_OPT_FUSED 4         /* the grouped path's fused hour (sampler workgroups and the placing blocks of their drivers in ONE launch per hour):
                                    1 on (default), 0 off = two launches per hour, 2 = on with placing blocks that give up waiting at once (the
-                                   tests' way into the bail-out: the step comes back with status bit 2 set and the context falls back to 0) */
+                                   tests' way into the bail-out: the step comes back with status bit 2 set and the context falls back to 0);
+                                   3 = the placing-first form (the PREVIOUS hour's placing blocks in front of the hour's sampler workgroups,
+                                   which wait for their zone's destination group; measured slower than 1 at Z = 4,096), 4 = 3
+                                   with sampler workgroups that give up waiting at once */
 #define CPM_OPT_FUSED_LAG 5     /* chunks of 64 sampler workgroups between a chunk and its placing blocks in the fused launch; at or above the number
                                    of chunks (the default): every sampler workgroup first, then every placing block */
 #define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
@@ -98,7 +101,7 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
 #define CPM_INFO_CAP_MULT 2
 #define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above FOUR times a workgroup's slots was seen
                             * (kHeavy in cpm_grouped.h; lighter overflow stays with the overflow rounds of the zone's own workgroup) */
-#define CPM_INFO_FUSED 4   /* 1 when the next grouped step runs the fused hour (one launch per hour), 0 when it takes two launches per hour: switched
+#define CPM_INFO_FUSED 4   /* 1 (3: in its placing-first form) when the next grouped step runs the fused hour (one launch per hour), 0 when it takes two launches per hour: switched
                             * off (CPM_OPT_FUSED), heavy buckets seen (CPM_INFO_PARTS > 1), rows / groups outside the fused instantiations, or
                             * a placing block once gave up waiting */
 int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);

@@ -21,7 +21,9 @@ s.solve_ivp(0x5EEDCA125, want=False)
 L = _lib.load()
 L.cpm_diag_place_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 zr = (Z + 7) & ~7
-nb = zr + ((Z + 63) // 64) * 32
+npl = ((Z + 63) // 64) * 32
+nb = zr + npl
+PF = os.environ.get("CPM_FUSED") == "3"   # placing first: the placing blocks of the hour before in front of the hour's samplers
 for _ in range(3):
     s.resample(0x5EEDCA125)
 _lib.check(L.cpm_diag_place_stamps(s._h, None, nb))
@@ -29,7 +31,7 @@ s.resample(0x5EEDCA125)
 buf = np.zeros((nb, 8), dtype=np.uint64)
 _lib.check(L.cpm_diag_place_stamps(s._h, buf.ctypes.data_as(C.c_void_p), nb))
 t = buf.astype(np.int64)
-role = np.r_[np.zeros(zr, dtype=int), np.ones(nb - zr, dtype=int)]   # 0 sampler workgroup, 1 placing block
+role = np.r_[np.ones(npl, dtype=int), np.zeros(zr, dtype=int)] if PF else np.r_[np.zeros(zr, dtype=int), np.ones(nb - zr, dtype=int)]   # 0 sampler workgroup, 1 placing block
 ok = t[:, 0] != 0
 print(f"blocks with stamps: {int(ok.sum())} of {nb} (samplers {int((ok & (role == 0)).sum())}, placing {int((ok & (role == 1)).sum())})")
 idx = np.flatnonzero(ok)
@@ -47,6 +49,8 @@ for c, (lo, hi) in enumerate(zip(np.r_[0, cuts], np.r_[cuts, len(idx)])):
     pe0, pe1, pe7 = t[pm, 0] - t0, t[pm, 1] - t0, t[pm, 7] - t0
     end = max(se7.max(), pe7.max())
     print(f"domain {c}: samplers {len(sm)}, placing {len(pm)}; launch span {end} ticks")
+    sd = np.diff(t[sm, :8], axis=1)
+    print(f"   sampler phases (median ticks) ids, Philox, pack+barrier, search, slots, barrier, flush: {[pct(sd[:, k], 50) for k in range(7)]}")
     print(f"   sampler entries 50/90/100 %: {pct(se0, 50)} {pct(se0, 90)} {se0.max()}   exits 50/90/99/100 %: {pct(se7, 50)} {pct(se7, 90)} {pct(se7, 99)} {se7.max()}"
           f"   lifetime median {pct(se7 - se0, 50)}")
     print(f"   placing entries 10/50/90/100 %: {pct(pe0, 10)} {pct(pe0, 50)} {pct(pe0, 90)} {pe0.max()}   past the wait 50/90/100 %: {pct(pe1, 50)} {pct(pe1, 90)} {pe1.max()}"
