@@ -396,7 +396,7 @@ def main():
     parking, driving = job.check(counts)
 
     # the other hourly kernel of the step, timed the same way outside the headline's timed region (none when the hour is ONE launch)
-    fused = kernel_used in (0, 5) and s.get_info(4) == 1
+    fused = kernel_used in (0, 5) and s.get_info(4) in (1, 3)   # (3: the placing-first form, CPM_FUSED=3)
     place_ms = []
     if kernel_used in (0, 5) and not fused:
         s.set_profile(True, stride=7, kernel=1)
