@@ -738,27 +738,20 @@ struct alignas(16) SampleLds {
 // A store / load of words that another workgroup of the SAME launch reads / has written (FUSED: the runs and run lengths, handed
 // from the sampler workgroups to the placing blocks of the fused hour): write-through past this XCD's L2 and past the reader's L1
 // (global_store / global_load ... sc1), as MI355X_MICROARCH.md's hand-off table prescribes.  !FUSED: plain.
-// (CPM_FUSED_ABLATE, tools/build_variants.sh: timing-only builds of the fused hour, results invalid -- 1: placing blocks return at once,
-//  2: placing blocks do not wait, 3: plain stores and no drain on the sampler side)
+// (Timing-only builds that left parts of the hand-off out -- placing blocks that do not wait, plain stores, no drain -- were used once
+//  to price it (profiles/round3_notes.md) and are gone: a block that reads runs which are not complete indexes memory with what it
+//  finds there, and one such build ended in a memory fault on the GPU.)
 template <bool FUSED>
 __device__ __forceinline__ void hand_store(uint32_t *p, uint32_t v)
 {
-#if defined(CPM_FUSED_ABLATE) && (CPM_FUSED_ABLATE == 3 || CPM_FUSED_ABLATE == 5)
-    *p = v;
-#else
     if constexpr (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
-#endif
 }
 template <bool FUSED>
 __device__ __forceinline__ uint32_t hand_load(const uint32_t *p)
 {
-#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE >= 4  // (4: plain loads in the placing blocks; 5: and plain stores, no drain)
-    return *p;
-#else
     if constexpr (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
-#endif
 }
 // FUSED: this workgroup's runs are complete -- every storing wave drains its stores, the workgroup meets, ONE lane counts the
 // workgroup in (agent-scope add on the counter of its chunk of origin zones; the placing blocks of that chunk poll it)
@@ -766,9 +759,7 @@ template <bool FUSED>
 __device__ __forceinline__ void hand_off_done(uint32_t *done_chunk, int tid)
 {
     if constexpr (FUSED) {
-#if !(defined(CPM_FUSED_ABLATE) && (CPM_FUSED_ABLATE == 3 || CPM_FUSED_ABLATE == 5))
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_s_barrier();
         if (tid == 0) __hip_atomic_fetch_add(done_chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1330,11 +1321,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     }
     if (tid == 0) s_any_long = 0;
     if (zs0 >= zs1) return;  // (uniform per block)
-#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE == 2
-    if constexpr (false) {
-#else
     if constexpr (FUSED) {
-#endif
         if (wave == 0) {
             bool ok = false;
             for (uint32_t spins = 0; spins < spin_limit; ++spins) {
@@ -1564,9 +1551,6 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
     if (z >= 0) {
         grouped_sample_body<kFusedThreads, CPT, NQ, true, true>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(z / kFusedChunk) * kDoneStride);
     } else {
-#if defined(CPM_FUSED_ABLATE) && CPM_FUSED_ABLATE == 1
-        return;
-#endif
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
 #ifdef CPM_PLACE_PRIO
         __builtin_amdgcn_s_setprio(CPM_PLACE_PRIO);

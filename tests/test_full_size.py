@@ -70,6 +70,11 @@ def test_melbourne_shaped_full_fleet_with_travel_times(cpm, O):
         s.init_states(C, cpz)
         assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"])
         r = s.resample(SIM_SEED, travel=True)
+        s.set_fused(3)                                  # the placing-first form of the hour at full size: the same counts
+        assert s.get_info(4) == 3
+        r3 = s.resample(SIM_SEED, travel=True)
+        assert s.get_info(4) == 3                       # (no sampler workgroup gave up or found its arrivals on another XCD)
+    assert np.array_equal(r3["parking"], ref["parking"]) and np.array_equal(r3["driving"], ref["driving"]) and r3["sum_tt_q16"] == ref["sum_tt_q16"]
     assert np.array_equal(r["parking"], ref["parking"])
     assert np.array_equal(r["driving"], ref["driving"])
     assert r["sum_tt_q16"] == ref["sum_tt_q16"]
