@@ -384,7 +384,7 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
 
 int32_t finish_ivp(cpm_ctx *c);
 
-// The travel table as sparse rows (once per datamatrix, behind k_build_travel_table): kept when the largest row -- its bitmap words
+// The travel table as sparse rows (once per datamatrix, straight from it): kept when the largest row -- its bitmap words
 // and its non-zero cells -- fits 32 KB of LDS; the travel kernel then stages an origin's row instead of gathering cells from HBM.
 int32_t build_sparse_travel_rows(cpm_ctx *c)
 {
@@ -406,7 +406,9 @@ int32_t build_sparse_travel_rows(cpm_ctx *c)
         unsigned long long *&p;
         ~Scratch2() { dfree(p); }
     } scratch2{d_total};
-    hipLaunchKernelGGL(cpm::k_tts_words, dim3(static_cast<unsigned>(rows)), dim3(64), 0, c->stream, c->d_tt, c->d_tts_words, d_count, static_cast<int>(c->Z), W);
+    const dim3 tgrid(nblk(c->Z, 64), static_cast<unsigned>(c->T), cpm::kTtsSplit);
+    hipLaunchKernelGGL(cpm::k_tts_bits, tgrid, dim3(64), 0, c->stream, c->d_dm, c->d_tts_words, static_cast<int>(c->Z), static_cast<int>(c->T), W);
+    hipLaunchKernelGGL(cpm::k_tts_prefix, dim3(nblk(rows, 256)), dim3(256), 0, c->stream, c->d_tts_words, d_count, rows, W);
     hipLaunchKernelGGL(cpm::k_tts_offsets, dim3(1), dim3(1024), 0, c->stream, d_count, c->d_tts_off, rows, d_max, d_total);
     HIP_TRY(hipGetLastError());
     uint32_t h_max = 0;
@@ -422,13 +424,12 @@ int32_t build_sparse_travel_rows(cpm_ctx *c)
         HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(double2) * std::max<size_t>(h_total, 1)));
         c->tts_cells_cap = h_total;
     }
-    hipLaunchKernelGGL(cpm::k_tts_cells, dim3(static_cast<unsigned>(rows)), dim3(64), 0, c->stream, c->d_tt, c->d_tts_words, c->d_tts_off, c->d_tts_cells,
-                       static_cast<int>(c->Z), W);
+    hipLaunchKernelGGL(cpm::k_tts_cells, tgrid, dim3(64), 0, c->stream, c->d_dm, c->d_tts_words, c->d_tts_off, c->d_tts_cells,
+                       static_cast<int>(c->Z), static_cast<int>(c->T), W);
     HIP_TRY(hipGetLastError());
     c->tts_lds = lds;
     c->tts_valid = true;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    dfree(c->d_tt);  // the dense table (Z x Z x T x 16 B: 2.1 GB at Melbourne's size) was only the way here; rebuilt with the next datamatrix
+    dfree(c->d_tt);  // (a dense table left over from a datamatrix whose rows did not fit)
     return CPM_OK;
 }
 
@@ -467,15 +468,17 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     if (kernel == CPM_KERNEL_ZONE_GROUPED) {
         if (!grouped_fits(c, c->zg.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR)");
-        if (travel && !c->tt_valid) {  // the travel table of the current datamatrix, once
-            const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
-            if (!c->d_tt) HIP_TRY(hipMalloc(&c->d_tt, sizeof(double2) * cells));
-            hipLaunchKernelGGL(cpm::k_build_travel_table, dim3(nblk(c->Z, cpm::kTtTile), nblk(c->Z, cpm::kTtTile), static_cast<unsigned>(c->T)),
-                               dim3(cpm::kTtTile * 8), 0, c->stream, c->d_dm, c->d_tt, static_cast<int>(c->Z), static_cast<int>(c->T));
-            HIP_TRY(hipGetLastError());
-            c->tt_valid = true;
+        if (travel && !c->tt_valid) {  // the travel rows of the current datamatrix, once: sparse rows for LDS, or -- rows too large -- the dense table
             int32_t rc_tts = build_sparse_travel_rows(c);
             if (rc_tts != CPM_OK) return rc_tts;
+            if (!c->tts_valid) {
+                const size_t cells = static_cast<size_t>(c->Z) * c->Z * c->T;
+                if (!c->d_tt) HIP_TRY(hipMalloc(&c->d_tt, sizeof(double2) * cells));
+                hipLaunchKernelGGL(cpm::k_build_travel_table, dim3(nblk(c->Z, cpm::kTtTile), nblk(c->Z, cpm::kTtTile), static_cast<unsigned>(c->T)),
+                                   dim3(cpm::kTtTile * 8), 0, c->stream, c->d_dm, c->d_tt, static_cast<int>(c->Z), static_cast<int>(c->T));
+                HIP_TRY(hipGetLastError());
+            }
+            c->tt_valid = true;
         }
         int32_t rc = cpm::grouped_run(c->zg, c->stream, grouped_tables(c), c->n, c->cars, c->d_zone0, seed, travel, d_counts, c->cu_count,
                                       [&](int what) { prof_begin(c, what); }, [&](int what) { prof_end(c, what); }, g_last_error);

@@ -1694,29 +1694,55 @@ __global__ __launch_bounds__(kTtTile * 8) void k_build_travel_table(const double
 
 // The travel table as SPARSE rows, for staging in LDS: real Uber Movement tables hold ~9 % of the (origin, destination, hour) cells
 // (README.md:302-310), so an origin's row of an hour is a bitmap of Z bits + ~200 cells of 16 B -- a few KB that the block of that
-// (origin, hour) brings into LDS once, instead of one scattered 16-B global load per driver (a line per lane: ~100 us of the ~300 us
-// the travel kernel took per resample at Z = 2,357).  Per row (t, o): words[w] = (bitmap of destinations 32 w .. 32 w + 31 with a
-// non-zero cell, number of non-zero cells of the row in front of word w), cells in destination order at cells[off[row] ...].
-// Built from the dense table in two passes of one wave per row (count, then fill); the offsets by one block.
-__global__ __launch_bounds__(64) void k_tts_words(const double2 *__restrict__ tt, uint2 *__restrict__ words, uint32_t *__restrict__ count, int Z, int W)
+// (origin, hour) brings into LDS once, instead of one scattered 16-B global load per driver.  Per row (t, o): words[w] = (bitmap of
+// destinations 32 w .. 32 w + 31 with a non-zero cell, number of non-zero cells of the row in front of word w), cells in destination
+// order at cells[off[row] ...].
+// Built straight from the datamatrix (reference layout [2][T][dest][origin]: the origin is the fastest index, so a wave takes 64
+// origins, lane = origin, and walks destinations -- every load a whole line): bitmaps (k_tts_bits), the cells in front of every
+// word and the rows' sizes (k_tts_prefix), the rows' offsets (k_tts_offsets, one block), the cells (k_tts_cells).  The dense
+// origin-major table this used to go through (2.1 GB written and read twice at Melbourne's size, allocated and freed per dataset)
+// is only built when a row does not fit LDS.
+constexpr int kTtsSplit = 4;   // parts of a row's words, one wave each (888 waves of 64 origins would leave most of the chip empty)
+constexpr int kTtsBatch = 16;  // destinations whose loads a lane has in flight together
+__global__ __launch_bounds__(64) void k_tts_bits(const double *__restrict__ dm, uint2 *__restrict__ words, int Z, int T, int W)
 {
-    const size_t row = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double2 *src = tt + row * Z;
-    uint32_t run = 0;
-    for (int d0 = 0; d0 < Z; d0 += 64) {
-        const int d = d0 + lane;
-        double2 c = make_double2(0.0, 0.0);
-        if (d < Z) c = src[d];
-        const unsigned long long m = ballot64(c.x != 0.0 || c.y != 0.0);
-        const uint32_t lo = static_cast<uint32_t>(m), hi = static_cast<uint32_t>(m >> 32);
-        if (lane == 0) {
-            words[row * W + d0 / 32] = make_uint2(lo, run);
-            if (d0 / 32 + 1 < W) words[row * W + d0 / 32 + 1] = make_uint2(hi, run + static_cast<uint32_t>(__popc(lo)));
+    const int o = blockIdx.x * 64 + threadIdx.x, t = blockIdx.y;
+    const int wper = (W + kTtsSplit - 1) / kTtsSplit, w0 = blockIdx.z * wper, w1 = min(W, w0 + wper);
+    if (o >= Z) return;
+    const size_t sd_off = static_cast<size_t>(Z) * Z * T;
+    const double *src = dm + static_cast<size_t>(o) + static_cast<size_t>(Z) * Z * t;  // + Z * d
+    uint2 *dst = words + (static_cast<size_t>(t) * Z + o) * W;
+    for (int w = w0; w < w1; ++w) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int h = 0; h < 32; h += kTtsBatch) {
+            double m[kTtsBatch], sdv[kTtsBatch];
+#pragma unroll
+            for (int u = 0; u < kTtsBatch; ++u) {
+                const int d = min(32 * w + h + u, Z - 1);
+                m[u] = src[static_cast<size_t>(Z) * d];
+                sdv[u] = src[static_cast<size_t>(Z) * d + sd_off];
+            }
+#pragma unroll
+            for (int u = 0; u < kTtsBatch; ++u)
+                if (32 * w + h + u < Z && (m[u] != 0.0 || sdv[u] != 0.0)) bits |= 1u << (h + u);
         }
-        run += static_cast<uint32_t>(__popcll(m));
+        dst[w] = make_uint2(bits, 0u);
     }
-    if (lane == 0) count[row] = run;
+}
+// words[row][w].y = non-zero cells of the row in front of word w; count[row] = the row's cells.  One lane per row.
+__global__ __launch_bounds__(256) void k_tts_prefix(uint2 *__restrict__ words, uint32_t *__restrict__ count, int64_t rows, int W)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= rows) return;
+    uint2 *wr = words + row * W;
+    uint32_t run = 0;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t bits = wr[w].x;
+        wr[w].y = run;
+        run += static_cast<uint32_t>(__popc(bits));
+    }
+    count[row] = run;
 }
 // off[r] = sum of count[0 .. r-1], off[rows] = total; *max_out = largest row.  One block (rows is T x Z: ~10^5).
 __global__ __launch_bounds__(1024) void k_tts_offsets(const uint32_t *__restrict__ count, uint32_t *__restrict__ off, int64_t rows, uint32_t *__restrict__ max_out,
@@ -1755,23 +1781,37 @@ __global__ __launch_bounds__(1024) void k_tts_offsets(const uint32_t *__restrict
     }
     if (tid == 1023) off[rows] = static_cast<uint32_t>(acc);
 }
-__global__ __launch_bounds__(64) void k_tts_cells(const double2 *__restrict__ tt, const uint2 *__restrict__ words, const uint32_t *__restrict__ off,
-                                                  double2 *__restrict__ cells, int Z, int W)
+__global__ __launch_bounds__(64) void k_tts_cells(const double *__restrict__ dm, const uint2 *__restrict__ words, const uint32_t *__restrict__ off,
+                                                  double2 *__restrict__ cells, int Z, int T, int W)
 {
-    const size_t row = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double2 *src = tt + row * Z;
+    const int o = blockIdx.x * 64 + threadIdx.x, t = blockIdx.y;
+    const int wper = (W + kTtsSplit - 1) / kTtsSplit, w0 = blockIdx.z * wper, w1 = min(W, w0 + wper);
+    if (o >= Z) return;
+    const size_t sd_off = static_cast<size_t>(Z) * Z * T;
+    const double *src = dm + static_cast<size_t>(o) + static_cast<size_t>(Z) * Z * t;
+    const size_t row = static_cast<size_t>(t) * Z + o;
+    const uint2 *wr = words + row * W;
     double2 *dst = cells + off[row];
-    for (int d0 = 0; d0 < Z; d0 += 64) {
-        const int d = d0 + lane;
-        if (d >= Z) continue;
-        const double2 c = src[d];
-        if (c.x != 0.0 || c.y != 0.0) {
-            // a cell as the travel kernel uses it: (mean, 1 / (2 sigma^2)) with sigma = std, or a tenth of the mean where the data hold
-            // no std (src/resampling.jl:65-67) -- the division of the sampler (truncnormal_pm10), done once per cell instead of per driver
-            const uint2 w = words[row * W + d / 32];
-            const double s1 = (c.y == 0) ? 0.1 * c.x : c.y;
-            dst[w.y + static_cast<uint32_t>(__popc(w.x & ((1u << (d & 31)) - 1u)))] = make_double2(c.x, truncnormal_inv2s2(s1));
+    for (int w = w0; w < w1; ++w) {
+        const uint2 word = wr[w];
+        uint32_t at = word.y;
+#pragma unroll
+        for (int h = 0; h < 32; h += kTtsBatch) {
+            double m[kTtsBatch], sdv[kTtsBatch];
+#pragma unroll
+            for (int u = 0; u < kTtsBatch; ++u) {
+                const int d = min(32 * w + h + u, Z - 1);
+                m[u] = src[static_cast<size_t>(Z) * d];
+                sdv[u] = src[static_cast<size_t>(Z) * d + sd_off];
+            }
+#pragma unroll
+            for (int u = 0; u < kTtsBatch; ++u)
+                if (word.x & (1u << (h + u))) {
+                    // a cell as the travel kernel uses it: (mean, 1 / (2 sigma^2)) with sigma = std, or a tenth of the mean where the data
+                    // hold no std (src/resampling.jl:65-67) -- the division of the sampler (truncnormal_pm10), done once per cell instead of per driver
+                    const double s1 = (sdv[u] == 0) ? 0.1 * m[u] : sdv[u];
+                    dst[at++] = make_double2(m[u], truncnormal_inv2s2(s1));
+                }
         }
     }
 }
