@@ -652,11 +652,11 @@ __device__ __forceinline__ void car_draw_words(uint64_t seed, uint64_t car, uint
 // One workgroup per origin zone.  (Resident workgroups each walking several zones, with or without the next zone's registers or
 // pack prefetched, were measured no faster; profiles/round1_notes.md.)
 // GROUPED: stayers compacted into next hour's bucket of the zone, drivers into the zone's fixed-size runs.  The drivers are
-//          first ranked and staged in LDS (kStage entries per group) and written out by 16 lanes per run, 64 B at a time;
+//          first ranked and staged in LDS (kStage entries per group) and written out by 8 lanes per run, 16 B per lane;
 //          ranks beyond kStage go to HBM directly.
 // !GROUPED: dest | drive << 31 per slot into ids_next (hour T of a resample: sampled, never applied, src/resampling.jl:81-83).
-// Order of a workgroup's life: the bucket size, the threshold, the ids and the row pack are requested together (the id loads are
-// clamped to the zone's REGION, not to its size, so they do not wait for the size); Philox runs while the pack is landing;
+// Order of a workgroup's life: the two ends' sizes and the threshold (scalar loads), then the ids (their positions depend on the
+// sizes since a bucket has two ends; clamped to the zone's region) and the row pack; Philox runs while the pack is landing;
 // after the barrier the CPT cars of a thread search in lockstep and take their slots with one stayer ticket per wave and CPT
 // rank atomics in flight together.
 #ifndef CPM_STAGE
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
 // ------------------------------------------------------------------------------------------------ placing the drivers
 // Drivers of destination group g -> their buckets.  blockIdx = j * kGroups + g: the blocks of a group share blockIdx % 8 (one XCD,
 // one L2: all writes to a bucket merge there; speed only, never correctness).  Block (g, j) takes the group-g runs of the origin
-// zones [j*zps, (j+1)*zps): 16 lanes per run, KDEEP entries per lane.  Run lengths and run contents sit at addresses known up
+// zones [j*zps, (j+1)*zps): 8 lanes per run, 2 x KDEEP entries per lane (16 x KDEEP of a run in registers).  Run lengths and run contents sit at addresses known up
 // front, so they are requested together.
 // Threads per block: 512 (128 origin zones per block, four blocks per CU; measured at S4k against 1024 x two per CU: 11.4 us against
 // 12.4 -- the kernel is a chain of round trips and barriers, and four shorter chains per CU interleave better than two; 256: 13.2),
@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
     }
 }
 
-// Geometry of a placing launch: threads per block, runs per 16-lane group (KRUNS = 4 or 8), blocks per destination group
+// Geometry of a placing launch: threads per block, runs per 16 threads (KRUNS = 4 or 8: KRUNS / 2 passes of the 8-lane segments), blocks per destination group
 struct PlaceShape {
     int pb, kruns, bpg;
 };
