@@ -884,81 +884,115 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         hand_off_done<FUSED>(done_chunk, tid);
         return;
     }
-    // Philox of the register-resident cars: needs the ids only
-    bool valid[CPT], drive[CPT], want[CPT], ok[CPT];
-    uint32_t dest[CPT], clo[CPT], khi[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n_all;
-        long long kb;
-        car_draw_words(a.seed, a.cars.global(id[c]), a.step, kb, clo[c], khi[c]);
-        drive[c] = valid[c] & (kb <= thr);       // u <= p_drive[origin,t] (src/resampling.jl:15) in integers
-        want[c] = drive[c] & (last != 0.0);      // stays, or zero row: destination = origin (:35-36)
-    }
-    // This wave's pieces of the pack have landed (LDS-DMA counts in vmcnt; s_barrier itself waits for no counter), then the
-    // barrier makes every wave's pieces visible to every wave.
-    CPM_SSTAMP(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    CPM_SSTAMP(3);
-    const uint32_t n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
-    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
-    const uint32_t *hi = pack + gw;
-    const uint32_t hi_last = hi[Z - 1];
-    const unsigned long long below = (1ull << lane) - 1ull;
+    // The register-resident cars: a wave's slots are tid + c * BLOCK, so of its CPT cars per lane the first k hold cars and the
+    // rest are empty for the WHOLE wave (k = the number of c with c * BLOCK + 64 * wave < n_all: wave-uniform).  Every empty slot ran
+    // Philox and the search like a full one -- at S4k 10.5 % of a launch's (car, wave) groups are empty (the buckets spread from half
+    // to two and a half times the mean) -- so the work below is written once for K live cars per lane and a wave runs the K it needs
+    // (the K cars of a lane still in lockstep).  Every wave meets the others at the one barrier inside, whatever its K.
     uint32_t nd = 0;
+    uint32_t n = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
     uint32_t *runs = GROUPED ? a.D + static_cast<size_t>(z) * kGroups * a.scap : nullptr;
-    pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
-    {
-        bool anyx = false;
+    const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
+    const uint32_t *hi = pack + gw;
+    uint32_t hi_last = 0;
+    auto first_pass = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        // Philox: needs the ids only
+        bool valid[K ? K : 1], drive[K ? K : 1], want[K ? K : 1], ok[K ? K : 1];
+        uint32_t dest[K ? K : 1], clo[K ? K : 1], khi[K ? K : 1];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
-            anyx |= want[c] & !ok[c];
+        for (int c = 0; c < K; ++c) {
+            valid[c] = static_cast<uint32_t>(tid + c * BLOCK) < n_all;
+            long long kb;
+            car_draw_words(a.seed, a.cars.global(id[c]), a.step, kb, clo[c], khi[c]);
+            drive[c] = valid[c] & (kb <= thr);       // u <= p_drive[origin,t] (src/resampling.jl:15) in integers
+            want[c] = drive[c] & (last != 0.0);      // stays, or zero row: destination = origin (:35-36)
         }
-        if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
+        // This wave's pieces of the pack have landed (LDS-DMA counts in vmcnt; s_barrier itself waits for no counter), then the
+        // barrier makes every wave's pieces visible to every wave.
+        CPM_SSTAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CPM_SSTAMP(3);
+        n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
+        hi_last = hi[Z - 1];
+        if constexpr (K > 0) {
+            pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+            {
+                bool anyx = false;
 #pragma unroll
-            for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
-        }
-    }
-    CPM_SSTAMP(4);
-    if (GROUPED) {
-        // stayers: one ticket per wave for all its CPT slots
-        unsigned long long mS[CPT];
-        uint32_t total = 0;
+                for (int c = 0; c < K; ++c) {
+                    dest[c] = want[c] ? dest[c] : static_cast<uint32_t>(z);
+                    anyx |= want[c] & !ok[c];
+                }
+                if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            mS[c] = ballot64(valid[c] & !drive[c]);
-            total += static_cast<uint32_t>(__popcll(mS[c]));
-        }
-        uint32_t bS = 0;
-        if (lane == 0 && total) bS = atomicAdd(&s_nstay, total);
-        bS = from_lane0(bS);
-        // drivers: CPT rank atomics in flight together
-        uint32_t rank[CPT];
+                    for (int c = 0; c < K; ++c)
+                        if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
+                }
+            }
+            CPM_SSTAMP(4);
+            if (GROUPED) {
+                // stayers: one ticket per wave for all its K slots
+                unsigned long long mS[K];
+                uint32_t total = 0;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+                for (int c = 0; c < K; ++c) {
+                    mS[c] = ballot64(valid[c] & !drive[c]);
+                    total += static_cast<uint32_t>(__popcll(mS[c]));
+                }
+                uint32_t bS = 0;
+                if (lane == 0 && total) bS = atomicAdd(&s_nstay, total);
+                bS = from_lane0(bS);
+                // drivers: K rank atomics in flight together
+                uint32_t rank[K];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            if (valid[c] & !drive[c]) put32(stay_out, bS + static_cast<uint32_t>(__popcll(mS[c] & below)), id[c]);
-            bS += static_cast<uint32_t>(__popcll(mS[c]));
-        }
+                for (int c = 0; c < K; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            if (drive[c]) {
-                const uint32_t g = dest[c] >> a.gshift;
-                const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
-                if (rank[c] < static_cast<uint32_t>(kStage)) stage[g * kStage + rank[c]] = packed;
-                else if (rank[c] < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank[c]], packed);
+                for (int c = 0; c < K; ++c) {
+                    if (valid[c] & !drive[c]) put32(stay_out, bS + static_cast<uint32_t>(__popcll(mS[c] & below)), id[c]);
+                    bS += static_cast<uint32_t>(__popcll(mS[c]));
+                }
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    if (drive[c]) {
+                        const uint32_t g = dest[c] >> a.gshift;
+                        const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                        if (rank[c] < static_cast<uint32_t>(kStage)) stage[g * kStage + rank[c]] = packed;
+                        else if (rank[c] < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank[c]], packed);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    if (valid[c]) stay_out[tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
+                    nd += drive[c] ? 1u : 0u;
+                }
             }
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            if (valid[c]) stay_out[tid + c * BLOCK] = dest[c] | (drive[c] ? kDriveBit : 0u);
-            nd += drive[c] ? 1u : 0u;
+    };
+    {
+        const uint32_t w64 = from_lane0(static_cast<uint32_t>(tid) & ~63u);  // (this wave's first slot of car 0, in a scalar register)
+        const uint32_t k = n_all > w64 ? min(static_cast<uint32_t>(CPT), (n_all - w64 + BLOCK - 1) / BLOCK) : 0u;
+        if constexpr (CPT == 4) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            case 2: first_pass(std::integral_constant<int, 2>{}); break;
+            case 3: first_pass(std::integral_constant<int, 3>{}); break;
+            default: first_pass(std::integral_constant<int, 4>{}); break;
+            }
+        } else if constexpr (CPT == 2) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            default: first_pass(std::integral_constant<int, 2>{}); break;
+            }
+        } else {
+            if (k == 0) first_pass(std::integral_constant<int, 0>{});
+            else first_pass(std::integral_constant<int, 1>{});
         }
     }
     for (uint32_t q0 = CPT * BLOCK; q0 < n; q0 += BLOCK) {  // buckets larger than CPT*BLOCK cars (wave-uniform trips)
