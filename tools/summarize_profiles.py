@@ -19,8 +19,9 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
+    # (a tag collected more than once holds every run's files: the newest)
     fs = glob.glob(os.path.join(src, pattern), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None
 
 
 stats = one("trace/**/*_kernel_stats.csv")
