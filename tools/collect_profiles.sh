@@ -10,7 +10,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-pair ${BENCH_ARGS}"  # (the side records stay in: table_build, per_dataset and skewed put their kernels into the same trace)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1
+# (the trace pass with more steps than the counter passes: the first launches of a run are cold and a kernel's AVERAGE is set against bench.py's own)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-pair ${BENCH_ARGS} > $OUT/bench_trace.log 2>&1
 echo trace done >> $OUT/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 echo fetch done >> $OUT/progress.log

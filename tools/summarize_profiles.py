@@ -27,7 +27,7 @@ def one(pattern):
 stats = one("trace/**/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-lines = [f"# {name}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pair` (--no-pair: without the two-resamples-in-flight section, whose launches overlap)", "",
+lines = [f"# {name}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-pair` (--no-pair: without the two-resamples-in-flight section, whose launches overlap)", "",
          "| kernel | calls | avg us | min us | max us | total ms | % |", "|---|---|---|---|---|---|---|"]
 for r in rows:
     lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
