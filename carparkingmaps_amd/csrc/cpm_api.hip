@@ -662,9 +662,10 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
     // development switches (tools/, A/B runs): the defaults of CPM_OPT_FUSED / CPM_OPT_FUSED_LAG
-    if (const char *v = std::getenv("CPM_FUSED")) {
+    if (const char *v = std::getenv("CPM_FUSED")) {  // (0, 1, 3 as CPM_OPT_FUSED; unset: 5 = where it pays)
         c->zg.fused_ok = std::atoi(v) != 0;
-        c->zg.fused_pf = std::atoi(v) >= 3;
+        c->zg.fused_pf = std::atoi(v) == 3;
+        c->zg.fused_auto = std::atoi(v) == 5;
     }
     if (const char *v = std::getenv("CPM_HEAVY_X")) c->zg.heavy_x_seen = static_cast<uint32_t>(std::max(1, std::min(16, std::atoi(v))));
     if (const char *v = std::getenv("CPM_FUSED_LAG")) c->zg.fused_lag = std::max(1, std::min(1 << 20, std::atoi(v)));
@@ -718,9 +719,10 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_FUSED:
-        if (value < 0 || value > 4) return fail(CPM_ERR_ARG, "fused hour %lld", (long long)value);
+        if (value < 0 || value > 5) return fail(CPM_ERR_ARG, "fused hour %lld", (long long)value);
         c->zg.fused_ok = value != 0;
-        c->zg.fused_pf = value >= 3;                                              // 3, 4: placing first (k_grouped_hour_pf)
+        c->zg.fused_auto = value == 5;                                            // 5: one launch per hour where it pays (the default)
+        c->zg.fused_pf = value == 3 || value == 4;                                // 3, 4: placing first (k_grouped_hour_pf)
         c->zg.fused_spin = (value == 2 || value == 4) ? 0u : cpm::kFusedSpinLimit;  // 2, 4: the waiting side gives up at once (tests of the bail-out)
         return CPM_OK;
     case CPM_OPT_FUSED_LAG:
@@ -757,7 +759,8 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         return CPM_OK;
     case CPM_INFO_FUSED:
         *value_out = (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zg.fused_ok && c->zg.parts <= 1 &&
-                      cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z))))
+                      cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z))) &&
+                      (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)), c->cu_count)))
                          ? (c->zg.fused_pf ? 3 : 1)
                          : 0;
         return CPM_OK;

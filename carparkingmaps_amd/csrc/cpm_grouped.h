@@ -2102,6 +2102,16 @@ inline bool fused_shape_ok(int Z, int Zq, int G)
     const int need = (pack_row_words(Zq, G) / 4 + kSampleBlock - 1) / kSampleBlock;
     return (1 << grouped_gshift_of(Z)) <= kFusedZpg && need <= 12;
 }
+// ... and where it PAYS.  MEASURED (one launch against two per hour, 1,000 cars per zone, interleaved runs on one box, ms per
+// resample): Z = 1,536: 0.524 / 0.493, 2,357: 0.664 / 0.650, 3,072: 0.710 / 0.727, 4,096: 0.868 / 0.912 (500 cars per zone: 0.703 /
+// 0.760, 2,000: 2.21 / 2.21), 5,120: 1.283 / 1.362, 6,144: 1.680 / 1.615, 8,192 x 500: 2.19 / 2.07.  It pays from two rounds of sampler
+// workgroups on (12 per CU) while the blocks' LDS -- every block of the fused launch carries the row pack's -- leaves five per
+// CU: below, the one launch has no second round to tuck its placing blocks behind; above, the placing blocks sit four to a CU.
+inline bool fused_pays(int Z, int Zq, int G, int cu_count)
+{
+    const size_t lds = fused_lds_bytes(Zq, G) + 4608;  // (+ the static part: SampleLds / PlaceLds)
+    return Z >= 12 * std::max(cu_count, 1) && 5 * lds <= 160 * 1024;
+}
 template <int CPT>
 inline void grouped_launch_hour_c(const GroupedArgs &a, hipStream_t stream)
 {
@@ -2298,6 +2308,7 @@ struct GroupedWork {
     uint32_t heavy_x_seen = 2;                                   // the heavy threshold (x a workgroup's slots) once heavy buckets were seen: the heavy launch runs
                                                                  // anyway then, and a bucket of 2-4 x the slots walked by ONE workgroup is the sampler's tail
     bool fused_ok = true;                                        // the fused hour is used (CPM_OPT_FUSED; cleared for good when a placing block gave up waiting)
+    bool fused_auto = true;                                      // ... where it pays (fused_pays); false: wherever an instantiation exists (CPM_OPT_FUSED set by the caller)
     bool fused_pf = false;                                       // ... in its placing-first form (k_grouped_hour_pf): the previous hour's placing blocks, then the samplers
     int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
                                                                  // every sampler workgroup first, then every placing block
@@ -2534,7 +2545,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.cars = cars;
         a.seed = seed;
         // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
-        const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G);
+        const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count));
         const bool pf = shape && w.fused_pf;  // (also the last hour, in its plain form: the placing of the hour before it rides in front)
         const bool fuse = grouped && !last_hour && shape && !pf;
         if (!pf) flush_pending();

@@ -62,7 +62,7 @@ class Sampler:
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_KERNEL, int(kernel)))
 
     def set_fused(self, mode=1, lag=None):
-        """The grouped path's fused hour: 1 on (default), 0 two launches per hour, 2 on with placing blocks that give up at once
+        """The grouped path's fused hour: 5 on where it pays (the library's default), 1 on wherever it can run, 0 two launches per hour, 2 on with placing blocks that give up at once
         (tests), 3 the placing-first form (the previous hour's placing blocks in front of the hour's samplers), 4 = 3 with samplers
         that give up at once (tests); lag: chunks of sampler workgroups in front of a chunk's placing blocks (mode 1)."""
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED, int(mode)))

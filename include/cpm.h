@@ -68,7 +68,9 @@ extern "C" {
 #define CPM_OPT_PROFILE 2       /* N >= 1: every N-th hourly launch of the profiled kernel carries a hipEvent pair stamped with the
                                    dispatch's own begin and end (hipExtLaunchKernelGGL); 0: off */
 #define CPM_OPT_FUSED 4         /* the grouped path's fused hour (sampler workgroups and the placing blocks of their drivers in ONE launch per hour):
-                                   1 on (default), 0 off = two launches per hour, 2 = on with placing blocks that give up waiting at once (the
+                                   5 (default) on where it pays -- from two rounds of sampler workgroups on (Z >= 12 x the CUs) while the row pack
+                                   leaves five blocks per CU (Z <= ~5,600): measured, DESIGN.md 4.1 --, 1 on wherever an instantiation exists,
+                                   0 off = two launches per hour, 2 = on with placing blocks that give up waiting at once (the
                                    tests' way into the bail-out: the step comes back with status bit 2 set and the context falls back to 0);
                                    3 = the placing-first form (the PREVIOUS hour's placing blocks in front of the hour's sampler workgroups,
                                    which wait for their zone's destination group; measured slower than 1 at Z = 4,096), 4 = 3

@@ -473,6 +473,24 @@ def test_fused_hour_equals_two_launches_per_hour(cpm, O, Z, cpz, T):
             assert s.get_info(2) == 4                            # ... and did not mistake it for an overflow
 
 
+@pytest.mark.parametrize("Z,want", [(1536, 0), (3072, 1), (4096, 1), (6144, 0)])
+def test_one_launch_per_hour_only_where_it_pays(cpm, Z, want):
+    """By default the hour is one launch where that was measured to pay (two rounds of sampler workgroups or more, a row pack that
+    leaves five blocks per CU: 3,072 <= Z <= ~5,600 on 256 CUs) and two launches elsewhere; CPM_OPT_FUSED = 1 forces it on."""
+    cpz, T = 200, 24
+    with cpm.Sampler(Z, T) as s:
+        s.synth_tables(TABLE_SEED)
+        s.init_states(Z * cpz, cpz)
+        assert s.get_info(1) == cpm.CPM_KERNEL_ZONE_GROUPED
+        if cpm.device_info(0)["cu_count"] == 256:
+            assert s.get_info(4) == want
+        s.set_fused(1)
+        assert s.get_info(4) == 1
+        s.set_fused(5)
+        r = s.resample(SIM_SEED)
+        assert (r["parking"].sum(axis=0) == Z * cpz).all()
+
+
 @pytest.mark.parametrize("deal", ["interleaved", "contiguous"])
 def test_two_hip_ranks_on_one_gpu_sum_to_the_single_run(cpm, deal):
     """The sharded path with HIP ranks side by side: two processes, each with its own context on the one GPU and its share of the
