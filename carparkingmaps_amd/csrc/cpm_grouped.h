@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
 {
     extern __shared__ uint32_t pack[];
     __shared__ uint32_t gb[kGroups], gbase[kGroups];
+    __shared__ uint32_t s_stay, s_sbase, s_nd;  // the block's stayers (sum of its waves'), their first slot in the bucket, its drivers
     const int Z = a.Z;
     const GroupedRare *rare = a.rare;
     if (blockIdx.x >= min(rare->nheavy[a.hour], rare->hgrid)) return;  // (the list of this hour is shorter than the grid)
@@ -1119,6 +1120,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const long long thr = a.thr_t[z];
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
     if (tid < kGroups) gb[tid] = 0;
+    if (tid == 0) {
+        s_stay = 0;
+        s_nd = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
@@ -1157,7 +1162,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             for (int c = 0; c < CPT; ++c)
                 if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
         }
-        // stayers: one global ticket per wave
+        // stayers: ONE global ticket per block (the waves' counts are added up in LDS first).  All the blocks of a heavy zone -- 37
+        // of them for the largest bucket of `--skew 32` -- draw on the zone's one stayer counter, its 32 run lengths and its driving
+        // count, and atomics on one address are served one after the other at the memory side: with a ticket per WAVE (and a driving
+        // count per wave) the heavy launch was 16 us per hour where its blocks' own work is 6.
         unsigned long long mS[CPT];
         uint32_t total = 0;
 #pragma unroll
@@ -1165,25 +1173,28 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             mS[c] = ballot64(valid[c] & !drive[c]);
             total += static_cast<uint32_t>(__popcll(mS[c]));
         }
-        uint32_t bS = 0;
-        if (lane == 0 && total) {
-            bS = atomicAdd(&a.cnt_next[z], total);
-            if (bS + total > cap) atomicOr(status, 2ull);
-        }
-        bS = from_lane0(bS);
+        uint32_t wS = 0;
+        if (lane == 0 && total) wS = atomicAdd(&s_stay, total);
+        wS = from_lane0(wS);
         uint32_t rank[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
             nd += drive[c] ? 1u : 0u;
         }
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const uint32_t p = bS + static_cast<uint32_t>(__popcll(mS[c] & below));
-            if ((valid[c] & !drive[c]) && p < cap) stay_out[p] = id[c];
-            bS += static_cast<uint32_t>(__popcll(mS[c]));
+        for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
+        if (lane == 0 && nd) atomicAdd(&s_nd, nd);
+        __syncthreads();  // the chunk's ranks and sums are final
+        if (tid == kGroups) {  // (a lane of the same wave as the 32 below: its ticket leaves with theirs)
+            const uint32_t all = s_stay;
+            uint32_t base = 0;
+            if (all) {
+                base = atomicAdd(&a.cnt_next[z], all);
+                if (base + all > cap) atomicOr(status, 2ull);
+            }
+            s_sbase = base;
+            if (s_nd) atomicAdd(&a.driving_t[z], static_cast<unsigned long long>(s_nd));
         }
-        __syncthreads();  // the chunk's ranks are final
         if (tid < kGroups) {
             const uint32_t c = gb[tid];
             uint32_t base = 0;
@@ -1195,6 +1206,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             gb[tid] = 0;
         }
         __syncthreads();
+        {
+            uint32_t bS = s_sbase + wS;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const uint32_t p = bS + static_cast<uint32_t>(__popcll(mS[c] & below));
+                if ((valid[c] & !drive[c]) && p < cap) stay_out[p] = id[c];
+                bS += static_cast<uint32_t>(__popcll(mS[c]));
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             if (drive[c]) {
@@ -1203,10 +1223,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
                 if (p < a.scap) runs[g * a.scap + p] = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
             }
         }
-        // (the next chunk writes gbase only behind its first barrier, which every thread reaches after these reads)
     }
-    for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
-    if (lane == 0 && nd) atomicAdd(&a.driving_t[z], static_cast<unsigned long long>(nd));
 }
 
 
