@@ -155,6 +155,30 @@ def test_travel_time_sum_for_every_block_size_of_the_travel_kernel(cpm, O, cpz):
     assert r["sum_tt_q16"] == ref["sum_tt_q16"]
 
 
+def test_travel_times_when_a_row_of_the_travel_table_does_not_fit_lds(cpm, O):
+    """Dense datamatrix at Z = 2,304: a row's non-zero cells (2,304 x 16 B) are more than the 32 KB the travel kernel stages, so the
+    grouped path builds the dense origin-major table and gathers from it (k_build_travel_table, k_grouped_travel<false>) -- the
+    same time sum as the oracle's, bit for bit."""
+    Z, T, cpz = 2304, 3, 40
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED + 5, density=1.0)
+    p_drive = O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5)
+    p_dest = O.createpdestin(dm, Z, T, 2)
+    ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+    with cpm.Sampler(Z, T) as s:
+        s.set_kernel(cpm.CPM_KERNEL_ZONE_GROUPED)
+        s.set_p_drive(p_drive)
+        s.set_p_dest(p_dest)
+        s.set_datamatrix(dm, dist)
+        s.init_states(C, cpz)
+        s.solve_ivp(SIM_SEED, want=False)
+        r = s.resample(SIM_SEED, travel=True)
+        assert s.get_info(1) == cpm.CPM_KERNEL_ZONE_GROUPED
+    assert np.array_equal(r["parking"], ref["parking"])
+    assert np.array_equal(r["driving"], ref["driving"])
+    assert r["sum_tt_q16"] == ref["sum_tt_q16"]
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_edge_rows(cpm, O, kernel):
     """Zero rows (dest = origin, still counted as driving: Appendix A-8), p_drive 0 / 1 / NaN zones
