@@ -1083,7 +1083,11 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
         hipLaunchKernelGGL(cpm::k_pdest_weights<24>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
     else
         hipLaunchKernelGGL(cpm::k_pdest_weights<0>, g1, dim3(256), 0, c->stream, c->d_dm, c->d_p, static_cast<int>(c->Z), static_cast<int>(c->T), e_dest, e_is_integer);
-    hipLaunchKernelGGL(cpm::k_pdest_normalise, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_p, static_cast<int>(c->Z));
+    // (row sums into the row-total array, which the row builder overwrites behind them)
+    if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(c->T * c->Z)));
+    hipLaunchKernelGGL(cpm::k_pdest_rowsum, dim3(nblk(c->Z, 64), static_cast<unsigned>(c->T)), dim3(64), 0, c->stream, c->d_p, c->d_last, static_cast<int>(c->Z));
+    hipLaunchKernelGGL(cpm::k_pdest_divide, dim3(nblk(c->Z, 256), nblk(c->Z, cpm::kDivBatch), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream, c->d_p,
+                       c->d_last, static_cast<int>(c->Z));
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, c->d_p, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) return fail(CPM_ERR_HIP, "build_p_dest: %s", hipGetErrorString(e));

@@ -158,16 +158,18 @@ __global__ __launch_bounds__(256) void k_pdest_weights(const double *__restrict_
 }
 
 // normalise per (i,t): nf = sum_j p[i,j,t], left to right here (the reference: Julia's pairwise sum(), createpdestin.jl:33); divide if nf > 0
-// (:38-46).  One lane per origin: a first sweep for the sum (32 loads in flight per lane, added in order), a second one that divides.
+// (:38-46).  Two kernels: the sums, one lane per origin (32 loads in flight per lane, added in order: T x Z lanes is all the
+// parallelism a sequential sum has), then the division over every entry at once -- as the second sweep of the summing lanes it ran
+// with those 888 waves' parallelism (0.77 ms for both sweeps at Z = 2,357; the division alone is a plain streaming pass).
 // (Dividing where the row tables are built instead -- inside the ONE lane per origin that forms the running sums -- was measured at
-// 1.58 ms against 0.64 + this kernel's second sweep at Z = 2,357: thirteen f64 instructions per entry in front of every addition.)
+// 1.58 ms against 0.64 + the dividing sweep at Z = 2,357: thirteen f64 instructions per entry in front of every addition.)
 constexpr int kSumBatch = 32;
-__global__ __launch_bounds__(64) void k_pdest_normalise(double *__restrict__ p, int Z)
+__global__ __launch_bounds__(64) void k_pdest_rowsum(const double *__restrict__ p, double *__restrict__ nf_out, int Z)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
     if (i >= Z) return;
-    double *row = p + static_cast<size_t>(t) * Z * Z + i;
+    const double *row = p + static_cast<size_t>(t) * Z * Z + i;
     double nf = 0.0;
     int j = 0;
     for (; j + kSumBatch <= Z; j += kSumBatch) {  // loads in batches, sum in order (see k_pdrive_mean)
@@ -178,17 +180,24 @@ __global__ __launch_bounds__(64) void k_pdest_normalise(double *__restrict__ p, 
         for (int u = 0; u < kSumBatch; ++u) nf = nf + v[u];
     }
     for (; j < Z; ++j) nf = nf + row[static_cast<size_t>(j) * Z];
-    if (nf > 0) {
-        j = 0;
-        for (; j + kSumBatch <= Z; j += kSumBatch) {
-            double v[kSumBatch];
+    nf_out[static_cast<size_t>(t) * Z + i] = nf;
+}
+// p[t][j][i] /= nf[t][i] where nf > 0: the origin on the lane (the reference's fastest index), kDivBatch destinations per thread
+constexpr int kDivBatch = 16;
+__global__ __launch_bounds__(256) void k_pdest_divide(double *__restrict__ p, const double *__restrict__ nf, int Z)
+{
+    const int t = blockIdx.z, j0 = blockIdx.y * kDivBatch;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Z) return;
+    const double f = nf[static_cast<size_t>(t) * Z + i];
+    if (!(f > 0)) return;
+    double *q = p + (static_cast<size_t>(t) * Z + j0) * Z + i;
+    double v[kDivBatch];
 #pragma unroll
-            for (int u = 0; u < kSumBatch; ++u) v[u] = row[static_cast<size_t>(j + u) * Z];
+    for (int u = 0; u < kDivBatch; ++u) v[u] = (j0 + u < Z) ? q[static_cast<size_t>(u) * Z] : 0.0;
 #pragma unroll
-            for (int u = 0; u < kSumBatch; ++u) row[static_cast<size_t>(j + u) * Z] = v[u] / nf;
-        }
-        for (; j < Z; ++j) row[static_cast<size_t>(j) * Z] = row[static_cast<size_t>(j) * Z] / nf;
-    }
+    for (int u = 0; u < kDivBatch; ++u)
+        if (j0 + u < Z) q[static_cast<size_t>(u) * Z] = v[u] / f;
 }
 
 }  // namespace cpm
