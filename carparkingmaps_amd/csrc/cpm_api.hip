@@ -129,6 +129,7 @@ struct cpm_ctx {
     int kernel = CPM_KERNEL_AUTO;
     bool profile = false;
     int prof_what = CPM_PROFILE_SAMPLER;  // CPM_OPT_PROFILE_KERNEL
+    int64_t fused_bailouts = 0;           // steps that came back with status bit 2 (a block of a one-launch form gave up waiting)
     int prof_stride = 1;      // bracket every prof_stride-th hourly sampler launch
     int64_t prof_seen = 0;    // sampler launches since profiling was switched on
     bool prof_open = false;
@@ -438,10 +439,14 @@ int32_t build_sparse_travel_rows(cpm_ctx *c)
 // region or a run overflowed: twice the regions while the problem still fits.  true: the step can be repeated on the grouped path.
 bool absorb_status(cpm_ctx *c, long long st)
 {
-    bool again = (st & 4) != 0;
-    if (again) c->zg.fused_ok = false;
-    if ((st & ~4ll) != 0) again = grow_grouped(c);
-    return again;
+    const bool bailed = (st & 4) != 0;
+    if (bailed && c->zg.fused_ok) {
+        c->zg.fused_ok = false;
+        ++c->fused_bailouts;  // (CPM_INFO_FUSED_BAILOUTS: the context has left the one-launch forms for good)
+    }
+    // (a step that bailed out AND overflowed: the two-launch path is tried on the regions as they are when they cannot grow)
+    const bool grown = (st & ~4ll) != 0 && grow_grouped(c);
+    return bailed || grown;
 }
 
 int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_counts)
@@ -661,14 +666,11 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
         cpm_destroy(c);
         return fail(CPM_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
-    // development switches (tools/, A/B runs): the defaults of CPM_OPT_FUSED / CPM_OPT_FUSED_LAG
-    if (const char *v = std::getenv("CPM_FUSED")) {  // (0, 1, 3 as CPM_OPT_FUSED; unset: 5 = where it pays)
-        c->zg.fused_ok = std::atoi(v) != 0;
-        c->zg.fused_pf = std::atoi(v) == 3;
-        c->zg.fused_auto = std::atoi(v) == 5;
-    }
+#ifdef CPM_DEV_ENV  // development builds only (tools/build_variants.sh ... "-DCPM_DEV_ENV"): the product reads nothing from the environment
+    if (const char *v = std::getenv("CPM_FUSED")) cpm_set_option(c, CPM_OPT_FUSED, std::atoi(v));
     if (const char *v = std::getenv("CPM_HEAVY_X")) c->zg.heavy_x_seen = static_cast<uint32_t>(std::max(1, std::min(16, std::atoi(v))));
-    if (const char *v = std::getenv("CPM_FUSED_LAG")) c->zg.fused_lag = std::max(1, std::min(1 << 20, std::atoi(v)));
+    if (const char *v = std::getenv("CPM_FUSED_LAG")) cpm_set_option(c, CPM_OPT_FUSED_LAG, std::atoi(v));
+#endif
     *ctx_out = c;
     return CPM_OK;
 }
@@ -719,11 +721,13 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->kernel = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_FUSED:
-        if (value < 0 || value > 5) return fail(CPM_ERR_ARG, "fused hour %lld", (long long)value);
+        if (value < 0 || value > 8) return fail(CPM_ERR_ARG, "fused hour %lld", (long long)value);
         c->zg.fused_ok = value != 0;
-        c->zg.fused_auto = value == 5;                                            // 5: one launch per hour where it pays (the default)
+        c->zg.fused_auto = value == 5;                                            // 5: where it pays
         c->zg.fused_pf = value == 3 || value == 4;                                // 3, 4: placing first (k_grouped_hour_pf)
-        c->zg.fused_spin = (value == 2 || value == 4) ? 0u : cpm::kFusedSpinLimit;  // 2, 4: the waiting side gives up at once (tests of the bail-out)
+        c->zg.fused_day = value >= 6;                                             // 6 .. 9: all hours of a run in one launch (k_grouped_day)
+        c->zg.day_mix = value == 8 ? 0 : 1;                                       // 8: its placing blocks in front of the sampler workgroups instead of among them
+        c->zg.fused_spin = (value == 2 || value == 4 || value == 7) ? 0u : cpm::kFusedSpinLimit;  // 2, 4, 7: the waiting side gives up at once (tests of the bail-out)
         return CPM_OK;
     case CPM_OPT_FUSED_LAG:
         if (value < 1 || value > (1 << 20)) return fail(CPM_ERR_ARG, "fused lag %lld", (long long)value);
@@ -761,8 +765,11 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         *value_out = (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zg.fused_ok && c->zg.parts <= 1 &&
                       cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z))) &&
                       (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)), c->cu_count)))
-                         ? (c->zg.fused_pf ? 3 : 1)
+                         ? (c->zg.fused_day ? 6 : (c->zg.fused_pf ? 3 : 1))
                          : 0;
+        return CPM_OK;
+    case CPM_INFO_FUSED_BAILOUTS:
+        *value_out = c->fused_bailouts;
         return CPM_OK;
     default:
         return fail(CPM_ERR_ARG, "unknown info %d", what);

@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 #include <string>
 
@@ -43,6 +44,16 @@ constexpr int kFusedThreads = 256;       // threads of every block of the fused 
 constexpr int kMaxZonesPerGroup = 1024;  // LDS bins of the place kernel
 constexpr uint32_t kHiMax = 0xFFFFFFFFu;
 constexpr int kMaxCapMult = 64;
+// Words that hand a zone over between workgroups of ONE launch (the day in one launch, cpm_day.h) carry flags beside their count:
+//   stayer-count word of (hour, zone): bit 31 = the zone's sampler workgroup of that hour is done (stayers, runs, run lengths complete),
+//   bit 30 = ... but it gave up (nothing of the zone was read or written: the step is invalid), bits 26..29 = the XCD it ran on.
+//   Every reader of a stayer count masks with kCntMask (counts are < 2^26: grouped_day_fits).
+//   hand-off counters: arrivals in the low 16 bits; a workgroup that gave up counts itself in with kDoneAbort on top, and whoever
+//   waits on a counter that carries such a mark gives up too (reads nothing, marks its own hand-offs): a bail-out drains the grid.
+constexpr uint32_t kCntValid = 0x80000000u, kCntAbort = 0x40000000u;
+constexpr int kCntXccShift = 26;
+constexpr uint32_t kCntMask = (1u << kCntXccShift) - 1u;
+constexpr uint32_t kDoneAbort = 0x10000u, kDoneCount = 0xFFFFu;
 
 // destination groups of 2^gshift consecutive zones, at most kGroups of them
 inline uint32_t grouped_gshift_of(int Z)
@@ -158,14 +169,17 @@ __global__ __launch_bounds__(kBucketBlock) void k_bucket_cars(const uint32_t *__
 // car-indexed state from fixed-stride buckets (end of the IVP): both ends of every region; a bucket whose ends met is flagged here
 // (the hour that filled it has no sampler launch behind it to notice)
 __global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt_s, const uint32_t *__restrict__ cnt_a, uint32_t cap,
-                           uint32_t *__restrict__ zone0, unsigned long long *status)
+                           uint32_t *__restrict__ zone0, uint32_t n, unsigned long long *status)
 {
     const uint32_t z = blockIdx.x;
-    const uint32_t ns_raw = cnt_s[z], na_raw = cnt_a[z];
+    const uint32_t ns_raw = cnt_s[z] & kCntMask, na_raw = cnt_a[z];  // (the day launch leaves flags beside the stayer counts)
     const uint32_t ns = min(ns_raw, cap), na = min(na_raw, cap - ns);
     if (threadIdx.x == 0 && static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(status, 2ull);
     const uint32_t gap = cap - ns - na;
-    for (uint32_t s = threadIdx.x; s < ns + na; s += blockDim.x) zone0[ids[static_cast<size_t>(z) * cap + s + (s >= ns ? gap : 0u)]] = z;
+    for (uint32_t s = threadIdx.x; s < ns + na; s += blockDim.x) {
+        const uint32_t id = ids[static_cast<size_t>(z) * cap + s + (s >= ns ? gap : 0u)];
+        if (id < n) zone0[id] = z;  // (ids of a step that is about to be rejected -- status != 0 -- may be anything)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ hourly sampler
@@ -204,6 +218,15 @@ struct GroupedArgs {
     // (ids / cnt_a above) before its sampler workgroups read them; pchunks = chunks of origin zones to place (0: nothing pending)
     const uint32_t *pD, *pcntg;
     int pchunks;
+    // the day in one launch (k_grouped_day, cpm_day.h): an hour's segment of the grid = the placing blocks of the hour before among
+    // this hour's sampler workgroups.  sdone: [chunks] lines, sampler workgroups of THIS hour that have handed their runs over (by
+    // chunk of origin zones); psdone: the same of the hour before (what the segment's placing blocks wait for); pdone: [kGroups]
+    // lines, the segment's placing blocks that are done (by destination group) and the XCDs they ran on; chained: this hour's
+    // buckets were written by blocks of the same launch (flags in cnt_s, every id load past the L1)
+    uint32_t *sdone;
+    const uint32_t *psdone;
+    uint32_t *pdone;
+    uint32_t chained;
     uint32_t cap, scap, idbits, gshift, step;
     // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
     //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
@@ -789,43 +812,61 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     // means the ids are in their registers.
     CPM_SSTAMP_DECL;
     CPM_SSTAMP(0);
-    const uint32_t ns_raw = a.cnt_s[z];
+    uint32_t ns_raw = a.cnt_s[z] & kCntMask;  // (a day launch leaves flags beside the stayer counts)
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     uint32_t na_raw;
     uint32_t id[CPT + 1];
     if constexpr (WAIT) {
+        // ONE wave learns whether the group's placing blocks are done and tells the others through LDS (the verdict must be the
+        // workgroup's: waves that disagreed would part ways at the barriers below); the others have their pieces of the pack in
+        // flight meanwhile.  A workgroup that gives up READS NOTHING the placing blocks may not have written: it takes its bucket
+        // for empty, so no stale or uninitialised word travels on as a car id or a destination (the step is invalid either way).
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x2 seen = {wait_need, 0u};  // {placing blocks of the group that have counted themselves in, the XCDs they ran on}
-        if (wait_need) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(seen) : "v"(0), "s"(wait_on) : "memory");
+        const bool poller = wait_need && tid < 64;
+        if (poller) asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(seen) : "v"(0), "s"(wait_on) : "memory");
         pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
-        if (wait_need) {
+        if (poller) {
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seen) : "n"(NQ) : "memory");
             uint32_t got = from_lane0(seen.x), where = from_lane0(seen.y);
-            for (uint32_t spins = 0; got < wait_need; ++spins) {  // (rare: the placing blocks come first in the launch)
+            for (uint32_t spins = 0; (got & kDoneCount) < wait_need; ++spins) {  // (rare: the placing blocks come first in the launch)
                 if (spins >= a.spin_limit) break;  // bounded: the step is then invalid, the context repeats it with two launches per hour
                 __builtin_amdgcn_s_sleep(32);
                 got = from_lane0(lane == 0 ? __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
                 where = from_lane0(lane == 0 ? __hip_atomic_load(wait_on + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
             }
             // (the mask is complete once the count is: a block ORs its XCD in before it counts itself in)
-            if ((got < wait_need || where != (1u << xcc_id())) && lane == 0) atomicOr(a.rare->status, 4ull);
+            const bool bad = (got & kDoneCount) < wait_need || (got >> 16) != 0u || where != (1u << xcc_id());
+            if (bad && lane == 0) atomicOr(a.rare->status, 4ull);
+            if (tid == 0) sl.pad_ = bad ? 1u : 0u;
         }
-        const uint32_t nsc = min(ns_raw, cap);
-        uint32_t nav;
-        asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(nav) : "v"(0), "s"(a.cnt_a + z) : "memory");
+        bool dead = false;
+        if (wait_need) {
+            lds_barrier();
+            dead = sl.pad_ != 0u;
+        }
+        const uint32_t nsc = dead ? 0u : min(ns_raw, cap);
+        uint32_t nav = 0;
+        if (!dead) {
+            asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(nav) : "v"(0), "s"(a.cnt_a + z) : "memory");
 #pragma unroll
-        for (int c = 0; c <= CPT; ++c) {
-            const uint32_t s1 = static_cast<uint32_t>(tid + c * BLOCK);
-            const uint32_t pos = s1 < nsc ? s1 : (cap - 1u + nsc - min(s1, cap - 1u + nsc));
-            asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(id[c]) : "v"(pos << 2), "s"(a.ids + b) : "memory");
+            for (int c = 0; c <= CPT; ++c) {
+                const uint32_t s1 = static_cast<uint32_t>(tid + c * BLOCK);
+                const uint32_t pos = s1 < nsc ? s1 : (cap - 1u + nsc - min(s1, cap - 1u + nsc));
+                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(id[c]) : "v"(pos << 2), "s"(a.ids + b) : "memory");
+            }
+            if constexpr (CPT == 4)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4])::"memory");
+            else if constexpr (CPT == 2)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1])::"memory");
+        } else {
+#pragma unroll
+            for (int c = 0; c <= CPT; ++c) id[c] = 0u;
+            ns_raw = 0u;
         }
-        if constexpr (CPT == 4)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4])::"memory");
-        else if constexpr (CPT == 2)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1]), "+v"(id[2])::"memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nav), "+v"(id[0]), "+v"(id[1])::"memory");
         na_raw = from_lane0(nav);
     } else {
         na_raw = a.cnt_a[z];
@@ -1110,7 +1151,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr uint32_t L = CPT * BLOCK;
     const uint32_t cap = a.cap;
-    const uint32_t ns = min(a.cnt_s[z], cap), na = min(a.cnt_a[z], cap - ns);
+    const uint32_t ns = min(a.cnt_s[z] & kCntMask, cap), na = min(a.cnt_a[z], cap - ns);
     const uint32_t n = ns + na, gap = cap - n;
     const uint32_t start0 = L * (1u + q);
     if (start0 >= n) return;
@@ -1304,7 +1345,7 @@ __device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &p
 // the surplus entries straight to their buckets (tbins: the running position inside each bucket)
 template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL>
 __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits,
-                                               int zg0, uint32_t cap, uint32_t *__restrict__ ids_next, uint32_t ltotal)
+                                               int zg0, int nzl, uint32_t cap, uint32_t *__restrict__ ids_next, uint32_t ltotal)
 {
     constexpr int kSurplusBatch = 4;
     const int tid = threadIdx.x;
@@ -1319,7 +1360,7 @@ __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, con
             if (e0 + u * PB < ltotal) {
                 const uint32_t dl = w[u] >> idbits;
                 const uint32_t p = atomicAdd(&pl.tbins[dl], 1u);
-                if (p < cap) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
+                if (p < cap && dl < static_cast<uint32_t>(nzl)) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
             }
     }
 }
@@ -1374,20 +1415,26 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     if (zs0 >= zs1) return;  // (uniform per block)
     if constexpr (FUSED) {
         if (wave == 0) {
-            bool ok = false;
+            uint32_t go = 0;  // 0: gave up waiting, 1: the chunk's runs are complete, 2: a sampler workgroup of the chunk gave up (kDoneAbort)
             for (uint32_t spins = 0; spins < spin_limit; ++spins) {
                 const uint32_t seen = from_lane0(lane == 0 ? __hip_atomic_load(done_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
-                if (seen >= need) {
-                    ok = true;
+                if ((seen & kDoneCount) >= need) {
+                    go = (seen >> 16) ? 2u : 1u;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(32);  // (~1 us between polls)
             }
-            if (tid == 0) pl.go = ok ? 1u : 0u;
+            if (tid == 0) pl.go = go;
         }
         lds_barrier();  // (the polling wave's loads come after its poll matched, the other waves' after this barrier)
-        if (pl.go == 0u) {
-            if (tid == 0) atomicOr(status, 4ull);
+        if (pl.go != 1u) {  // nothing is read, nothing is stored
+            if (tid == 0) {
+                if (pl.go == 0u) atomicOr(status, 4ull);
+                if constexpr (SIGNAL) {  // whoever waits for this block gives up too, at once
+                    __hip_atomic_fetch_or(done_out + 1, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(done_out, 1u + kDoneAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             return;
         }
     }
@@ -1494,14 +1541,18 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
         }
 #pragma unroll
         for (int u = 0; u < kOutBatch; ++u)
-            if (i0 + u * kPlaceBlock < total && p[u] < cap)
+            if (i0 + u * kPlaceBlock < total && p[u] < cap && dl[u] < static_cast<uint32_t>(nzl))
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
-    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL>(pl, D, g, zs0, zs1, scap, idbits, zg0, cap, ids_next, ltotal);
+    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL>(pl, D, g, zs0, zs1, scap, idbits, zg0, nzl, cap, ids_next, ltotal);
     CPM_PSTAMP(7);
 #if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER) && !defined(CPM_STAMP_BOTH)
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
+#endif
+#if defined(CPM_DIAGNOSTIC) && defined(CPM_STAMP_BOTH)
+    st_[0] = (st_[0] & ~0xFFull) | ((__builtin_amdgcn_s_getreg((4) | (8 << 6) | (7 << 11))) & 0xFFu);  // HW_REG_HW_ID bits 8..15: cu, sh, se
+    st_[7] = (st_[7] & ~0x1Full) | xcc_id();
 #endif
     CPM_PSTAMP_FLUSH;
     if constexpr (SIGNAL) {
@@ -2287,6 +2338,10 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
     }
 }
 
+}  // namespace cpm
+#include "cpm_day.h"  // the hours of a run in ONE launch (k_grouped_day), built from the bodies above
+namespace cpm {
+
 // ------------------------------------------------------------------------------------------------ workspace and driver
 // run capacity: a quarter of a bucket region (= the mean bucket size at cap_mult 4), >= 64, whole 128-B lines
 inline uint32_t grouped_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
@@ -2327,6 +2382,9 @@ struct GroupedWork {
     bool fused_ok = true;                                        // the fused hour is used (CPM_OPT_FUSED; cleared for good when a placing block gave up waiting)
     bool fused_auto = true;                                      // ... where it pays (fused_pays); false: wherever an instantiation exists (CPM_OPT_FUSED set by the caller)
     bool fused_pf = false;                                       // ... in its placing-first form (k_grouped_hour_pf): the previous hour's placing blocks, then the samplers
+    bool fused_day = false;                                      // ... as ONE launch for all hours of a run but the last (k_grouped_day, cpm_day.h)
+    int day_mix = 1;                                             // its block order: placing blocks among the sampler workgroups (1) or in front of them (0)
+    GroupedArgs *day_hours = nullptr;                            // [T] the hours' arguments of a day launch (device memory, filled by k_grouped_zero)
     int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
                                                                  // every sampler workgroup first, then every placing block
     uint32_t fused_spin = kFusedSpinLimit;
@@ -2336,7 +2394,7 @@ struct GroupedWork {
     GroupedRare *rare = nullptr;                                 // what the rare branches of the hourly kernels read (written by k_grouped_zero per run)
     uint32_t *maxn = nullptr;                                    // [2] of the current run: largest heavy bucket (> kHeavy x the sampler workgroup's slots), most heavy buckets in one hour
     uint32_t *heavy_list = nullptr, *nheavy = nullptr;           // [kHeavyCap] zones handed to the heavy kernel this hour; [T+1] how many, per hour
-    int run_hours = 2;                                           // copies of Dq / cntg: 2 (alternating hours), or T when the runs of every hour of a resample are kept (ensure_history)
+    int run_hours = kDayRunCopies;                               // copies of Dq / cntg: 3 (rotating), or T when the runs of every hour of a resample are kept (ensure_history)
     int parts = 1;                                               // workgroups per heavy zone: 1 + blocks of the heavy kernel (set_parts)
     int hgrid = 0;                                               // zones the heavy launch covers
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
@@ -2351,7 +2409,8 @@ struct GroupedWork {
 
     size_t fused_chunks() const { return static_cast<size_t>(std::max((Z + kFusedChunk - 1) / kFusedChunk, kGroups)); }  // (counter lines per hour: by chunk, or by group)
     size_t done_base() const { return (static_cast<size_t>(T + 1) * 2 * Z + kDoneStride - 1) / kDoneStride * kDoneStride; }  // (whole lines)
-    size_t cnt_words() const { return done_base() + static_cast<size_t>(T) * fused_chunks() * kDoneStride; }
+    size_t pdone_base() const { return done_base() + static_cast<size_t>(T) * fused_chunks() * kDoneStride; }  // (day launch: [T][kGroups] lines behind the chunk counters)
+    size_t cnt_words() const { return pdone_base() + static_cast<size_t>(T + 1) * kGroups * kDoneStride; }
     size_t run_words() const { return static_cast<size_t>(Z) * kGroups * scap; }
     size_t len_words() const { return static_cast<size_t>(Z) * kGroups; }
     // Room for the runs of all T hours (travel times in one launch at the end of a resample), when they fit 24 GiB; else one copy.
@@ -2385,8 +2444,10 @@ struct GroupedWork {
         maxn = nullptr;
         if (rare) (void)hipFree(rare);
         rare = nullptr;
+        if (day_hours) (void)hipFree(day_hours);
+        day_hours = nullptr;
         n = 0;
-        run_hours = 2;
+        run_hours = kDayRunCopies;
         buckets0_valid = false;
     }
 
@@ -2414,15 +2475,16 @@ struct GroupedWork {
         alloc(&idsB, slots);
         alloc(&cnt0, 2 * static_cast<size_t>(Z));
         alloc(&cnt, cnt_words());
-        alloc(&Dq, 2 * static_cast<size_t>(Z) * kGroups * scap);  // (two hours: the placing-first hour reads the last hour's runs while this hour's are written)
-        alloc(&cntg, 2 * static_cast<size_t>(Z) * kGroups);
-        run_hours = 2;
+        alloc(&Dq, kDayRunCopies * static_cast<size_t>(Z) * kGroups * scap);  // (three hours: what the day launch rotates over, cpm_day.h; the hourly launches alternate between two)
+        alloc(&cntg, kDayRunCopies * static_cast<size_t>(Z) * kGroups);
+        run_hours = kDayRunCopies;
         alloc(&heavy_list, kHeavyCap);
         alloc(&nheavy, static_cast<size_t>(T) + 1);
         if (e == hipSuccess) e = hipMalloc(&tt_part, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMemset(tt_part, 0, sizeof(unsigned long long) * kTravelParts);
         if (e == hipSuccess) e = hipMalloc(&maxn, 2 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&rare, sizeof(GroupedRare));
+        if (e == hipSuccess) e = hipMalloc(&day_hours, sizeof(GroupedArgs) * static_cast<size_t>(std::max(T, 1)));
         if (e != hipSuccess) release();
         return e;
     }
@@ -2448,7 +2510,7 @@ struct GroupedTables {
 // stored by the sampler).  (Five hipMemsetAsync calls were five ~5 us fill kernels in the stream of every resample, 2.5 % of it.)
 __global__ __launch_bounds__(256) void k_grouped_zero(unsigned long long *__restrict__ counts, size_t nwords, uint32_t *__restrict__ maxn,
                                                       uint32_t *__restrict__ nheavy, int nh, uint32_t *__restrict__ cnt, size_t ncnt,
-                                                      GroupedRare *__restrict__ rare, GroupedRare rare_now)
+                                                      GroupedRare *__restrict__ rare, GroupedRare rare_now, GroupedArgs *__restrict__ hours, GroupedDay day)
 {
     const size_t stride = static_cast<size_t>(gridDim.x) * 256;
     for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < nwords; i += stride) counts[i] = 0ull;
@@ -2457,6 +2519,7 @@ __global__ __launch_bounds__(256) void k_grouped_zero(unsigned long long *__rest
         if (threadIdx.x < 2) maxn[threadIdx.x] = 0u;
         if (threadIdx.x == 0) *rare = rare_now;  // (what the rare branches of this run's kernels read)
         for (int k = threadIdx.x; k < nh; k += 256) nheavy[k] = 0u;
+        for (int k = threadIdx.x; k < day.nhours; k += 256) day_fill_hour(day, k, hours + k);  // (the arguments of a day launch's hours)
     }
 }
 
@@ -2489,6 +2552,64 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     unsigned long long *driving = parking + static_cast<size_t>(T) * Z;
     unsigned long long *tt_sum = parking + 2 * static_cast<size_t>(T) * Z;
     unsigned long long *status = tt_sum + 1;
+    // travel times: from the runs, by one launch per hour -- or, when the runs of all hours fit, by one launch at the end
+    const bool history = travel && !ivp && w.ensure_history();
+    const int G = pack_guide_bits(Z);
+    const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G));
+    const int64_t mean = (n + Z - 1) / Z;
+    const int hours = ivp ? T - 1 : T;
+    // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
+    const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count));
+    // ... and one launch for ALL hours that are applied (k_grouped_day): the IVP's T - 1, a resample's first T - 1 (hour T is sampled,
+    // never applied: the plain form behind the placing of hour T - 1, k_grouped_hour_pf); hourly travel launches need hourly boundaries
+    const int day_n = (shape && w.fused_day && w.cap < (1u << kCntXccShift) && (!travel || history)) ? (ivp ? hours : hours - 1) : 0;
+    const int nchunk = (Z + kFusedChunk - 1) / kFusedChunk;
+    GroupedDay day{};
+    auto hour_base = [&](GroupedArgs &a) {  // what all hours of a run share
+        a.rare = w.rare;
+        a.Z = Z;
+        a.Zq = tb.Zq;
+        a.G = G;
+        a.cap = w.cap;
+        a.scap = w.scap;
+        a.idbits = w.idbits;
+        a.gshift = w.gshift;
+        a.cars = cars;
+        a.seed = seed;
+        a.lag = w.fused_lag;
+        a.heavy_x = w.parts > 1 ? w.heavy_x_seen : kHeavy;
+        a.spin_limit = w.fused_spin;
+        a.sdone = a.pdone = nullptr;
+        a.psdone = nullptr;
+        a.chained = 0;
+    };
+    if (day_n >= 2) {
+        std::memset(&day.base, 0, sizeof(day.base));
+        hour_base(day.base);
+        day.ids0 = w.ids0;
+        day.cnt0 = w.cnt0;
+        day.idsA = w.idsA;
+        day.idsB = w.idsB;
+        day.cnt = w.cnt;
+        day.rp = tb.rp;
+        day.last = tb.last;
+        day.thr = tb.thr;
+        day.Dq = w.Dq;
+        day.cntg = w.cntg;
+        day.parking = parking;
+        day.driving = driving;
+        day.sdone0 = w.cnt + w.done_base();
+        day.pdone0 = w.cnt + w.pdone_base();
+        day.rw = rw;
+        day.run_words = w.run_words();
+        day.len_words = w.len_words();
+        day.sdone_stride = w.fused_chunks() * kDoneStride;
+        day.pdone_stride = static_cast<size_t>(kGroups) * kDoneStride;
+        day.copies = w.run_hours;
+        day.nchunk = nchunk;
+        day.nhours = day_n;
+        day.step0 = static_cast<uint32_t>(ivp ? 0 : T - 1);
+    }
     {
         const size_t nwords = 2 * static_cast<size_t>(T) * Z + 2;
         const unsigned zgrid = static_cast<unsigned>(std::min<size_t>((nwords + 255) / 256, 1024));
@@ -2502,7 +2623,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         rn.hgrid = static_cast<uint32_t>(w.hgrid);
         rn.parts = static_cast<uint32_t>(w.parts);
         rn.Z = Z;
-        hipLaunchKernelGGL(k_grouped_zero, dim3(zgrid), dim3(256), 0, stream, parking, nwords, w.maxn, w.nheavy, T + 1, w.cnt, w.cnt_words(), w.rare, rn);
+        hipLaunchKernelGGL(k_grouped_zero, dim3(zgrid), dim3(256), 0, stream, parking, nwords, w.maxn, w.nheavy, T + 1, w.cnt, w.cnt_words(), w.rare, rn, w.day_hours, day);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zeroing the counters");
     }
     if (!w.buckets0_valid) {  // bucket the car-indexed state once; reused until the state changes
@@ -2512,13 +2633,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "initial bucketing");
         w.buckets0_valid = true;
     }
-    // travel times: from the runs, by one launch per hour -- or, when the runs of all hours fit, by one launch at the end
-    const bool history = travel && !ivp && w.ensure_history();
-    const int G = pack_guide_bits(Z);
-    const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G));
-    const int64_t mean = (n + Z - 1) / Z;
     const uint32_t *ids = w.ids0, *cnt = w.cnt0;
-    const int hours = ivp ? T - 1 : T;
     // placing first: the drivers of the hour before, still in their runs, wait for the next launch to move them into `ids` / `cnt`
     const uint32_t *pend_D = nullptr, *pend_cntg = nullptr;
     auto flush_pending = [&]() {  // ... or for a placing launch of their own, when that launch is not of the placing-first kind
@@ -2528,7 +2643,20 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         prof_end(CPM_PROFILE_PLACE);
         pend_D = pend_cntg = nullptr;
     };
-    for (int t = 0; t < hours; ++t) {
+    int t_first = 0;
+    if (day_n >= 2) {
+        prof_begin(CPM_PROFILE_SAMPLER);
+        grouped_launch_day(w.day_hours, day_n, Z, tb.Zq, G, static_cast<int>(w.gshift), nchunk, w.day_mix, mean, stream);
+        prof_end(CPM_PROFILE_SAMPLER);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone day launch");
+        // the drivers of its last hour are still in their runs: placed in front of hour T's sampler workgroups, or by a launch of their own
+        t_first = day_n;
+        ids = ((day_n - 1) & 1) ? w.idsB : w.idsA;
+        cnt = w.cnt + static_cast<size_t>(day_n) * 2 * Z;
+        pend_D = w.Dq + w.run_words() * static_cast<size_t>((day_n - 1) % w.run_hours);
+        pend_cntg = w.cntg + w.len_words() * static_cast<size_t>((day_n - 1) % w.run_hours);
+    }
+    for (int t = t_first; t < hours; ++t) {
         const uint32_t step = static_cast<uint32_t>(ivp ? t : T - 1 + t);
         // hour T of a resample is sampled, never applied (src/resampling.jl:81-83): counts only -- unless its travel times are wanted,
         // which are computed from the runs
@@ -2537,43 +2665,32 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         uint32_t *cnt_next = w.cnt + static_cast<size_t>(t + 1) * 2 * Z;  // stayers; the arrivals Z words behind
         uint32_t *ids_next = (t & 1) ? w.idsB : w.idsA;
         GroupedArgs a;
+        hour_base(a);
         a.ids = ids;
         a.cnt_s = cnt;
         a.cnt_a = cnt + Z;
         a.rp_t = tb.rp + static_cast<size_t>(t) * Z * rw;
         a.last_t = tb.last + static_cast<size_t>(t) * Z;
         a.thr_t = tb.thr + static_cast<size_t>(t) * Z;
-        a.rare = w.rare;
         a.hour = t;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
-        a.D = w.Dq + w.run_words() * (history ? t : (t & 1));
-        a.cntg = w.cntg + w.len_words() * (history ? t : (t & 1));
+        a.D = w.Dq + w.run_words() * (history ? t : (t % w.run_hours));
+        a.cntg = w.cntg + w.len_words() * (history ? t : (t % w.run_hours));
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
-        a.Z = Z;
-        a.Zq = tb.Zq;
-        a.G = G;
-        a.cap = w.cap;
-        a.scap = w.scap;
-        a.idbits = w.idbits;
-        a.gshift = w.gshift;
         a.step = step;
-        a.cars = cars;
-        a.seed = seed;
-        // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
-        const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count));
-        const bool pf = shape && w.fused_pf;  // (also the last hour, in its plain form: the placing of the hour before it rides in front)
+        const bool after_day = day_n >= 2 && t == t_first;  // (the hour behind a day launch: its placing rides in front, whatever the context's own form)
+        const bool pf = shape && (w.fused_pf || after_day);  // (also the last hour, in its plain form: the placing of the hour before it rides in front)
         const bool fuse = grouped && !last_hour && shape && !pf;
         if (!pf) flush_pending();
         a.pD = pend_D;
         a.pcntg = pend_cntg;
-        a.pchunks = pend_D ? (Z + kFusedChunk - 1) / kFusedChunk : 0;
+        a.pchunks = pend_D ? nchunk : 0;
         pend_D = pend_cntg = nullptr;
-        a.done_t = w.cnt + w.done_base() + static_cast<size_t>(t) * w.fused_chunks() * kDoneStride;
-        a.lag = w.fused_lag;
-        a.heavy_x = w.parts > 1 ? w.heavy_x_seen : kHeavy;
-        a.spin_limit = w.fused_spin;
+        // hand-off counters of the hour: by chunk (k_grouped_hour) or by group (k_grouped_hour_pf; behind a day launch: a segment of their own)
+        a.done_t = after_day ? w.cnt + w.pdone_base() + static_cast<size_t>(t) * kGroups * kDoneStride
+                             : w.cnt + w.done_base() + static_cast<size_t>(t) * w.fused_chunks() * kDoneStride;
         prof_begin(CPM_PROFILE_SAMPLER);
         if (pf && grouped) grouped_launch_hour_pf<true>(a, mean, stream);
         else if (pf) grouped_launch_hour_pf<false>(a, mean, stream);
@@ -2643,7 +2760,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     }
     flush_pending();  // (an IVP ends on a placing: its final buckets are read below)
     if (ivp) {
-        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, cnt + Z, w.cap, d_zone0_out, status);
+        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, cnt + Z, w.cap, d_zone0_out, static_cast<uint32_t>(n), status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
         w.ivp_ids = ids;
         w.ivp_cnt = cnt;

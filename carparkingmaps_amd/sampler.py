@@ -64,7 +64,9 @@ class Sampler:
     def set_fused(self, mode=1, lag=None):
         """The grouped path's fused hour: 5 on where it pays (the library's default), 1 on wherever it can run, 0 two launches per hour, 2 on with placing blocks that give up at once
         (tests), 3 the placing-first form (the previous hour's placing blocks in front of the hour's samplers), 4 = 3 with samplers
-        that give up at once (tests); lag: chunks of sampler workgroups in front of a chunk's placing blocks (mode 1)."""
+        that give up at once (tests); 6 all hours of a run in ONE launch (k_grouped_day: the placing blocks of an hour among the next
+        hour's sampler workgroups, which draw for their stayers first), 8 = 6 with the placing blocks in front, 7 = 6 with blocks that
+        give up at once (tests), 9 = 6 where it pays; lag: chunks of sampler workgroups in front of a chunk's placing blocks (mode 1)."""
         _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED, int(mode)))
         if lag is not None:
             _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED_LAG, int(lag)))

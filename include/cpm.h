@@ -74,7 +74,12 @@ extern "C" {
                                    tests' way into the bail-out: the step comes back with status bit 2 set and the context falls back to 0);
                                    3 = the placing-first form (the PREVIOUS hour's placing blocks in front of the hour's sampler workgroups,
                                    which wait for their zone's destination group; measured slower than 1 at Z = 4,096), 4 = 3
-                                   with sampler workgroups that give up waiting at once */
+                                   with sampler workgroups that give up waiting at once;
+                                   6 = ALL hours of a run but the last in ONE launch (k_grouped_day, csrc/cpm_day.h: an hour's placing blocks in
+                                   front of / among the next hour's sampler workgroups, which draw for their stayers first when the placing is
+                                   not done yet; measured slower than 1 at every size tried), 8 = 6 with every placing block of an
+                                   hour in front of every sampler workgroup of the next, 7 = 6 with blocks that give up waiting at once.
+                                   The library reads no environment variable. */
 #define CPM_OPT_FUSED_LAG 5     /* chunks of 64 sampler workgroups between a chunk and its placing blocks in the fused launch; at or above the number
                                    of chunks (the default): every sampler workgroup first, then every placing block */
 #define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
@@ -103,7 +108,8 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
 #define CPM_INFO_CAP_MULT 2
 #define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above FOUR times a workgroup's slots was seen
                             * (kHeavy in cpm_grouped.h; lighter overflow stays with the overflow rounds of the zone's own workgroup) */
-#define CPM_INFO_FUSED 4   /* 1 (3: in its placing-first form) when the next grouped step runs the fused hour (one launch per hour), 0 when it takes two launches per hour: switched
+#define CPM_INFO_FUSED_BAILOUTS 5 /* steps so far that came back with status bit 2 (a block of a one-launch form gave up waiting: the context then keeps to two launches per hour) */
+#define CPM_INFO_FUSED 4   /* 1 (3: in its placing-first form, 6: all hours in one launch) when the next grouped step runs the fused hour (one launch per hour), 0 when it takes two launches per hour: switched
                             * off (CPM_OPT_FUSED), heavy buckets seen (CPM_INFO_PARTS > 1), rows / groups outside the fused instantiations, or
                             * a placing block once gave up waiting */
 int32_t cpm_get_info(cpm_ctx *ctx, int32_t what, int64_t *value_out);

@@ -482,18 +482,20 @@ def test_fused_hour_equals_two_launches_per_hour(cpm, O, Z, cpz, T):
         p_dest = s.build_p_dest(2)
         ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
         s.set_kernel(5)
-        # (3: the placing-first form -- the previous hour's placing blocks in front of the hour's samplers; 2, 4: the bail-outs)
-        for mode, lag in [(1, 1), (0, None), (1, 2), (1, 7), (1, 1 << 20), (3, None), (2, None), (3, None), (4, None)]:
+        # (3: the placing-first form -- the previous hour's placing blocks in front of the hour's samplers; 6, 8: all hours of a run in
+        #  ONE launch, k_grouped_day, placing blocks among / in front of the sampler workgroups; 2, 4, 7: the bail-outs)
+        for mode, lag in [(1, 1), (0, None), (1, 2), (1, 7), (1, 1 << 20), (3, None), (2, None), (3, None), (4, None), (6, None), (8, None),
+                          (7, None), (6, None)]:
             s.set_fused(mode, lag)
             s.init_states(C, cpz)
-            assert s.get_info(4) == {0: 0, 1: 1, 2: 1, 3: 3, 4: 3}[mode]
+            assert s.get_info(4) == {0: 0, 1: 1, 2: 1, 3: 3, 4: 3, 6: 6, 7: 6, 8: 6}[mode]
             assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"]), (mode, lag)
             r = s.resample(SIM_SEED, travel=True)
             assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (mode, lag)
             assert r["sum_tt_q16"] == ref["sum_tt_q16"], (mode, lag)
             r = s.resample(SIM_SEED)                             # (without travel times the last hour runs in its plain form)
             assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (mode, lag)
-            assert s.get_info(4) == {0: 0, 1: 1, 2: 0, 3: 3, 4: 0}[mode]   # after a bail-out the context keeps to two launches
+            assert s.get_info(4) == {0: 0, 1: 1, 2: 0, 3: 3, 4: 0, 6: 6, 7: 0, 8: 6}[mode]   # after a bail-out the context keeps to two launches
             assert s.get_info(2) == 4                            # ... and did not mistake it for an overflow
 
 
