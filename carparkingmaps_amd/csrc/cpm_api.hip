@@ -16,6 +16,7 @@
 #include "cpm_tables.h"
 #include "cpm_exact.h"
 #include "cpm_grouped.h"
+#include "cpm_dataset.h"
 #include "cpm_ingest.h"
 
 static hipError_t ensure_stream(cpm_ctx *c);
@@ -93,6 +94,25 @@ struct cpm_ctx {
     double2 *d_tts_cells = nullptr;
     size_t tts_cells_cap = 0, tts_lds = 0;
     bool tts_valid = false;
+    bool tts_fixed = false;  // the travel rows are those of the compact dataset: fixed stride kDsCap, counts in d_ds_cnt
+    // the current datamatrix as compact rows (cpm_dataset.h: ONE sweep of it; valid until it changes), when it is sparse enough
+    cpm::DsCell *d_ds_cells = nullptr;  // [T*Z][kDsCap] cells of every (hour, origin), sorted by destination
+    uint32_t *d_ds_cnt = nullptr;       // [T*Z] cells per row; then {longest row, a row outgrew its capacity}
+    uint32_t *h_ds_stats = nullptr;     // pinned twin of those two words
+    bool ds_valid = false;              // the rows describe the current datamatrix (ds_ok: and are usable)
+    bool ds_ok = false;
+    int ds_max = 0;                     // longest row
+    // ... and the p_destin tables built from them (k_ds_pdest): sparse packs in d_hi, what a tie walks in these three (owned by the
+    // TABLE: they stay whole when the next dataset's cells arrive)
+    double *d_sp = nullptr;             // [T*Z][kDsCap] normalised p of every row's cells
+    uint32_t *d_sj = nullptr;           // ... their destinations
+    uint32_t *d_scnt = nullptr;         // [T*Z] cells per row
+    bool sparse_tables = false;         // the installed p_destin tables are of that kind: d_p holds p_destin only when p_dense_valid
+    bool p_dense_valid = false;
+    double tab_e_dest = 2.0;            // the exponent they were built with (cpm_refresh_tables)
+    int tab_e_int = 1;
+    size_t hi_words_alloc = 0;          // words d_hi was allocated for
+    int pk_G = 0, pk_Zc = 0;            // geometry of the packs in d_hi (with Zq): guide bits, entries in front of the pad
     double *d_pdrive_mean = nullptr;  // [T][Z] mean_sum of createpdrive (src/createpdrive.jl:10-21): depends on datamatrix and dist only,
     bool pdrive_mean_valid = false;   // so the model-selection sweep (p_min, p_max, e_drive vary) computes it once
     bool have_pdrive = false, have_cdf = false, have_dmat = false, have_dist = false;
@@ -212,9 +232,19 @@ hipError_t launch_build_rows(cpm_ctx *c)
     }
     dim3 grid(nblk(c->Z, cpm::kRowTile), static_cast<unsigned>(c->T));
     hipLaunchKernelGGL((cpm::k_build_rows<CDF, PACK>), grid, dim3(cpm::kRowBlock), cpm::kRowLds, c->stream, c->d_p, CDF ? c->d_cdf : nullptr,
-                       PACK ? c->d_hi : nullptr, c->d_last, c->d_ckpt, static_cast<int>(c->Z), c->Zp, c->Zq,
+                       PACK ? c->d_hi : nullptr, c->d_last, c->d_ckpt, static_cast<int>(c->Z), c->Zp, cpm::pack_zq(static_cast<int>(c->Z)),
                        cpm::pack_guide_bits(static_cast<int>(c->Z)), c->d_err);
     return hipGetLastError();
+}
+
+int32_t ensure_hi(cpm_ctx *c, size_t words)
+{
+    if (c->d_hi && c->hi_words_alloc >= words) return CPM_OK;
+    dfree(c->d_hi);
+    c->hi_words_alloc = 0;
+    HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * std::max<size_t>(words, 1)));
+    c->hi_words_alloc = words;
+    return CPM_OK;
 }
 
 // The table in d_p -> everything the samplers read: row totals, checkpoints and -- when a row pack fits LDS -- the row packs
@@ -229,8 +259,15 @@ int32_t build_rows(cpm_ctx *c, bool with_cdf)
     c->cdf_full = false;
     if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
     if (!c->d_ckpt) HIP_TRY(hipMalloc(&c->d_ckpt, sizeof(double) * static_cast<size_t>(rows) * cpm::ckpt_count(static_cast<int>(c->Z))));
-    if (pack && !c->d_hi)
-        HIP_TRY(hipMalloc(&c->d_hi, sizeof(uint32_t) * static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))));
+    c->sparse_tables = false;  // (dense packs of the table in d_p)
+    c->p_dense_valid = true;
+    c->Zq = cpm::pack_zq(static_cast<int>(c->Z));
+    c->pk_G = cpm::pack_guide_bits(static_cast<int>(c->Z));
+    c->pk_Zc = static_cast<int>(c->Z);
+    if (pack) {
+        int32_t rc_hi = ensure_hi(c, static_cast<size_t>(rows) * cpm::pack_row_words(c->Zq, c->pk_G));
+        if (rc_hi != CPM_OK) return rc_hi;
+    }
     if (cdf && !c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * static_cast<size_t>(rows) * c->Zp));
     hipError_t e_rows;
     if (cdf && pack) e_rows = launch_build_rows<true, true>(c);
@@ -245,11 +282,30 @@ int32_t build_rows(cpm_ctx *c, bool with_cdf)
     return CPM_OK;
 }
 
+// p_destin in the reference's layout when the installed tables came from a compact dataset (cpm_dataset.h): only for what reads it --
+// a caller that wants the array, the kernels that search f64 rows
+int32_t ensure_dense_p(cpm_ctx *c)
+{
+    if (!c->sparse_tables || c->p_dense_valid) return CPM_OK;
+    const size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
+    if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
+    HIP_TRY(hipMemsetAsync(c->d_p, 0, bytes, c->stream));
+    hipLaunchKernelGGL(cpm::k_ds_dense_p, dim3(cpm::ds_grid(c->T * c->Z)), dim3(cpm::kDsThreads * cpm::kDsRows), 0, c->stream, c->d_sp, c->d_sj, c->d_scnt,
+                       cpm::kDsCap, c->T * c->Z, static_cast<int>(c->Z), c->d_p);
+    HIP_TRY(hipGetLastError());
+    c->p_dense_valid = true;
+    return CPM_OK;
+}
+
 // the canonical f64 CDF rows of the installed table, for the kernels that search them (enqueued on the context's stream)
 int32_t ensure_full_cdf(cpm_ctx *c)
 {
     if (c->cdf_full) return CPM_OK;
     if (!c->have_cdf) return fail(CPM_ERR_STATE, "p_dest not set");
+    {
+        int32_t rc_p = ensure_dense_p(c);
+        if (rc_p != CPM_OK) return rc_p;
+    }
     if (!c->d_cdf) HIP_TRY(hipMalloc(&c->d_cdf, sizeof(double) * static_cast<size_t>(c->T * c->Z) * c->Zp));
     double *keep_last = c->d_last, *keep_ckpt = c->d_ckpt;  // (already built: this pass writes the CDF rows only)
     c->d_last = nullptr;
@@ -265,7 +321,7 @@ int32_t ensure_full_cdf(cpm_ctx *c)
 
 bool grouped_fits(const cpm_ctx *c, int cap_mult)
 {
-    return c->d_hi && c->d_last && c->d_ckpt && c->d_thr && cpm::grouped_path_fits(c->n, static_cast<int>(c->Z), cap_mult);
+    return c->d_hi && c->d_last && (c->d_ckpt || c->sparse_tables) && c->d_thr && cpm::grouped_path_fits(c->n, static_cast<int>(c->Z), cap_mult);
 }
 
 // AUTO: a zone-bucketed LDS path when a row fits in LDS and there are enough cars per zone to amortise streaming every row once
@@ -308,10 +364,23 @@ cpm::GroupedTables grouped_tables(const cpm_ctx *c)
         tb.tts_W = static_cast<int>((c->Z + 31) / 32);
         tb.tts_lds = c->tts_lds;
     }
+    if (c->tts_valid && c->tts_fixed) {  // (travel rows of a compact dataset: fixed stride, counts beside them)
+        tb.tts_cnt = c->d_ds_cnt;
+        tb.tts_stride = cpm::kDsCap;
+    }
     tb.Z = static_cast<int>(c->Z);
     tb.Zp = c->Zp;
     tb.Zq = c->Zq;
     tb.T = static_cast<int>(c->T);
+    tb.G = c->pk_G;
+    tb.Zc = c->pk_Zc;
+    tb.smap = c->sparse_tables ? 1 : 0;
+    if (c->sparse_tables) {
+        tb.sp = c->d_sp;
+        tb.sj = c->d_sj;
+        tb.scnt = c->d_scnt;
+        tb.scap = cpm::kDsCap;
+    }
     return tb;
 }
 
@@ -385,11 +454,99 @@ int32_t launch_histogram(cpm_ctx *c, int64_t *d_counts)
 
 int32_t finish_ivp(cpm_ctx *c);
 
+// The current datamatrix as compact rows (cpm_dataset.h), once per datamatrix: ONE sweep of it (k_ds_cells), then the rows sorted and
+// the travel rows written from them (k_ds_sort).  ds_ok: every row fits its capacity and the sparse pack of the longest row is at most
+// 60 % of the dense one -- else the dense builders of cpm_tables.h / cpm_grouped.h take the dataset, as they take every T != 24.
+int32_t ensure_dataset(cpm_ctx *c)
+{
+    if (c->ds_valid) return CPM_OK;
+    c->ds_ok = false;
+    if (!cpm::ds_fits(c->Z, c->T) || !cpm::pack_row_fits(static_cast<int>(c->Z))) {
+        c->ds_valid = true;
+        return CPM_OK;
+    }
+    const int64_t rows = c->T * c->Z;
+    const int W = static_cast<int>((c->Z + 31) / 32);
+    if (!c->d_ds_cells) HIP_TRY(hipMalloc(&c->d_ds_cells, sizeof(cpm::DsCell) * static_cast<size_t>(rows) * cpm::kDsCap));
+    if (!c->d_ds_cnt) HIP_TRY(hipMalloc(&c->d_ds_cnt, sizeof(uint32_t) * static_cast<size_t>(rows + 2)));
+    if (!c->h_ds_stats) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_ds_stats), 2 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(c->d_ds_cnt, 0, sizeof(uint32_t) * static_cast<size_t>(rows + 2), c->stream));
+    hipLaunchKernelGGL(cpm::k_ds_cells, dim3(nblk(c->Z, 64), nblk(c->Z, cpm::kDsJB)), dim3(256), 0, c->stream, c->d_dm, c->d_ds_cells, c->d_ds_cnt,
+                       static_cast<int>(c->Z), cpm::kDsCap, c->d_ds_cnt + rows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_ds_stats, c->d_ds_cnt + rows, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ds_max = static_cast<int>(std::max<uint32_t>(c->h_ds_stats[0], 1u));
+    c->ds_valid = true;
+    const int zq_c = cpm::pack_zq(c->ds_max), g_c = cpm::pack_guide_bits(c->ds_max);
+    const int dense_words = cpm::pack_row_words(cpm::pack_zq(static_cast<int>(c->Z)), cpm::pack_guide_bits(static_cast<int>(c->Z)));
+    if (c->h_ds_stats[1] != 0 || 10 * cpm::pack_row_words(zq_c, g_c, 1) > 6 * dense_words) return CPM_OK;  // dense: the builders of cpm_tables.h
+    if (!c->d_tts_words) HIP_TRY(hipMalloc(&c->d_tts_words, sizeof(uint2) * static_cast<size_t>(rows) * W));
+    if (c->tts_cells_cap < static_cast<size_t>(rows) * cpm::kDsCap) {
+        dfree(c->d_tts_cells);
+        c->tts_cells_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(double2) * static_cast<size_t>(rows) * cpm::kDsCap));
+        c->tts_cells_cap = static_cast<size_t>(rows) * cpm::kDsCap;
+    }
+    const size_t lds_sort = sizeof(uint32_t) * 2 * W * cpm::kDsRows;
+    hipLaunchKernelGGL(cpm::k_ds_sort, dim3(cpm::ds_grid(rows)), dim3(cpm::kDsThreads * cpm::kDsRows), lds_sort, c->stream, c->d_ds_cells, c->d_ds_cnt, cpm::kDsCap,
+                       rows, static_cast<int>(c->Z), c->d_tts_words, W, c->d_tts_cells);
+    HIP_TRY(hipGetLastError());
+    c->ds_ok = true;
+    // the travel rows of this datamatrix are those just written: bitmap words + the longest row's cells must fit the travel kernel's LDS
+    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(c->ds_max) * sizeof(double2);
+    if (lds <= 32 * 1024) {
+        c->tts_lds = lds;
+        c->tts_valid = true;
+        c->tts_fixed = true;
+        c->tt_valid = true;
+        dfree(c->d_tt);  // (a dense table left over from a datamatrix whose rows did not fit)
+    }
+    return CPM_OK;
+}
+
+// createpdestin on the compact rows (k_ds_pdest): sparse packs, row totals and what a tie walks; false when this dataset / exponent
+// takes the dense builders (x^0 = 1 also where x = 0: every cell of the dense table then holds weight)
+int32_t build_p_dest_sparse(cpm_ctx *c, double e_dest, int32_t e_is_integer, bool *done)
+{
+    *done = false;
+    if (!(e_dest > 0.0)) return CPM_OK;
+    int32_t rc = ensure_dataset(c);
+    if (rc != CPM_OK || !c->ds_ok) return rc;
+    const int64_t rows = c->T * c->Z;
+    const int nc = c->ds_max, zq_c = cpm::pack_zq(nc), g_c = cpm::pack_guide_bits(nc);
+    if (!c->d_sp) HIP_TRY(hipMalloc(&c->d_sp, sizeof(double) * static_cast<size_t>(rows) * cpm::kDsCap));
+    if (!c->d_sj) HIP_TRY(hipMalloc(&c->d_sj, sizeof(uint32_t) * static_cast<size_t>(rows) * cpm::kDsCap));
+    if (!c->d_scnt) HIP_TRY(hipMalloc(&c->d_scnt, sizeof(uint32_t) * static_cast<size_t>(rows)));
+    if (!c->d_last) HIP_TRY(hipMalloc(&c->d_last, sizeof(double) * static_cast<size_t>(rows)));
+    rc = ensure_hi(c, static_cast<size_t>(rows) * cpm::pack_row_words(zq_c, g_c, 1));
+    if (rc != CPM_OK) return rc;
+    c->have_cdf = false;
+    c->cdf_full = false;
+    hipLaunchKernelGGL(cpm::k_ds_pdest, dim3(cpm::ds_grid(rows)), dim3(cpm::kDsThreads * cpm::kDsRows), 0, c->stream, c->d_ds_cells, c->d_ds_cnt, cpm::kDsCap,
+                       rows, static_cast<int>(c->Z), e_dest, e_is_integer, nc, zq_c, g_c, c->d_hi, c->d_last, c->d_sp, c->d_sj, c->d_scnt, c->d_err);
+    HIP_TRY(hipGetLastError());
+    c->sparse_tables = true;
+    c->p_dense_valid = false;
+    c->Zq = zq_c;
+    c->pk_G = g_c;
+    c->pk_Zc = nc;
+    c->tab_e_dest = e_dest;
+    c->tab_e_int = e_is_integer;
+    rc = check_err_flag(c, "p_dest holds NaN or negative entries (reference: BoundsError, Appendix A-7)", CPM_ERR_TABLE);
+    if (rc != CPM_OK) return rc;
+    c->have_cdf = true;
+    c->zx.tables_dirty = true;
+    *done = true;
+    return CPM_OK;
+}
+
 // The travel table as sparse rows (once per datamatrix, straight from it): kept when the largest row -- its bitmap words
 // and its non-zero cells -- fits 32 KB of LDS; the travel kernel then stages an origin's row instead of gathering cells from HBM.
 int32_t build_sparse_travel_rows(cpm_ctx *c)
 {
     c->tts_valid = false;
+    c->tts_fixed = false;
     const int64_t rows = c->T * c->Z;
     const int W = static_cast<int>((c->Z + 31) / 32);
     if (!c->d_tts_words) HIP_TRY(hipMalloc(&c->d_tts_words, sizeof(uint2) * static_cast<size_t>(rows) * W));
@@ -473,7 +630,11 @@ int32_t resample_enqueue(cpm_ctx *c, uint64_t seed, uint32_t flags, int64_t *d_c
     if (kernel == CPM_KERNEL_ZONE_GROUPED) {
         if (!grouped_fits(c, c->zg.cap_mult))
             return fail(CPM_ERR_ARG, "CPM_KERNEL_ZONE_GROUPED does not fit this problem (use CPM_KERNEL_ZONE_LDS or CPM_KERNEL_CAR)");
-        if (travel && !c->tt_valid) {  // the travel rows of the current datamatrix, once: sparse rows for LDS, or -- rows too large -- the dense table
+        if (travel && !c->tt_valid) {  // the travel rows of the current datamatrix, once: with its compact rows (cpm_dataset.h) ...
+            int32_t rc_ds = ensure_dataset(c);
+            if (rc_ds != CPM_OK) return rc_ds;
+        }
+        if (travel && !c->tt_valid) {  // ... or, datasets those do not take: sparse rows for LDS, or -- rows too large -- the dense table
             int32_t rc_tts = build_sparse_travel_rows(c);
             if (rc_tts != CPM_OK) return rc_tts;
             if (!c->tts_valid) {
@@ -648,6 +809,8 @@ int32_t cpm_create(cpm_ctx **ctx_out, int64_t Z, int64_t T, int32_t device_id)
     c->T = T;
     c->Zp = static_cast<int>((Z + 15) / 16 * 16);
     c->Zq = cpm::pack_zq(static_cast<int>(Z));
+    c->pk_G = cpm::pack_guide_bits(static_cast<int>(Z));
+    c->pk_Zc = static_cast<int>(Z);
     c->device = device_id;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->cu_count = p.multiProcessorCount;
@@ -690,6 +853,12 @@ int32_t cpm_destroy(cpm_ctx *c)
     dfree(c->d_dm);
     dfree(c->d_dist);
     dfree(c->d_pdrive_mean);
+    dfree(c->d_ds_cells);
+    dfree(c->d_ds_cnt);
+    dfree(c->d_sp);
+    dfree(c->d_sj);
+    dfree(c->d_scnt);
+    if (c->h_ds_stats) (void)hipHostFree(c->h_ds_stats);
     dfree(c->d_tt);
     dfree(c->d_tts_words);
     dfree(c->d_tts_off);
@@ -763,10 +932,13 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
         return CPM_OK;
     case CPM_INFO_FUSED:
         *value_out = (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zg.fused_ok && c->zg.parts <= 1 &&
-                      cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z))) &&
-                      (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)), c->cu_count)))
+                      cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, c->pk_G, c->sparse_tables) &&
+                      (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, c->pk_G, c->cu_count, c->sparse_tables)))
                          ? (c->zg.fused_day ? 6 : (c->zg.fused_pf ? 3 : 1))
                          : 0;
+        return CPM_OK;
+    case CPM_INFO_SPARSE_TABLES:
+        *value_out = c->sparse_tables ? cpm::pack_row_words(c->Zq, c->pk_G, 1) : 0;
         return CPM_OK;
     case CPM_INFO_FUSED_BAILOUTS:
         *value_out = c->fused_bailouts;
@@ -849,6 +1021,7 @@ int32_t cpm_set_datamatrix(cpm_ctx *c, const double *datamatrix, const double *d
     c->have_dmat = false;
     c->tt_valid = false;
     c->tts_valid = false;
+    c->ds_valid = false;
     c->pdrive_mean_valid = false;
     HIP_TRY(hipMemcpyAsync(c->d_dm, datamatrix, bytes, hipMemcpyHostToDevice, c->stream));
     if (dist) HIP_TRY(hipMemcpyAsync(c->d_dist, dist, dbytes, hipMemcpyHostToDevice, c->stream));
@@ -879,6 +1052,7 @@ static int32_t datamatrix_from_device_rows(cpm_ctx *c, const double *d_raw, int6
     c->have_dmat = false;
     c->tt_valid = false;
     c->tts_valid = false;
+    c->ds_valid = false;
     c->pdrive_mean_valid = false;
     HIP_TRY(hipMemsetAsync(c->d_dm, 0, sizeof(double) * cells * 2, c->stream));  // zeros(number_zones, number_zones, T, 2) (:7)
     if (n == 0) {
@@ -1051,9 +1225,16 @@ int32_t cpm_build_p_drive(cpm_ctx *c, double p_min, double p_max, double e_drive
     size_t bytes = sizeof(double) * c->Z * c->T;
     if (!c->d_pdrive) HIP_TRY(hipMalloc(&c->d_pdrive, bytes));
     if (!c->d_pdrive_mean) HIP_TRY(hipMalloc(&c->d_pdrive_mean, bytes));
-    if (!c->pdrive_mean_valid) {  // the Z x Z x T pass over the datamatrix: once per datamatrix / distance matrix
-        dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
-        hipLaunchKernelGGL(cpm::k_pdrive_mean, grid, dim3(64), 0, c->stream, c->d_dm, c->d_dist, c->d_pdrive_mean, static_cast<int>(c->Z));
+    if (!c->pdrive_mean_valid) {  // once per datamatrix / distance matrix: from the dataset's compact rows, or the Z x Z x T pass over the datamatrix
+        int32_t rc_ds = ensure_dataset(c);
+        if (rc_ds != CPM_OK) return rc_ds;
+        if (c->ds_ok) {
+            hipLaunchKernelGGL(cpm::k_ds_pdrive, dim3(cpm::ds_grid(c->T * c->Z)), dim3(cpm::kDsThreads * cpm::kDsRows), 0, c->stream, c->d_ds_cells, c->d_ds_cnt,
+                               cpm::kDsCap, c->T * c->Z, static_cast<int>(c->Z), c->d_dist, c->d_pdrive_mean);
+        } else {
+            dim3 grid(nblk(c->Z, 64), static_cast<unsigned>(c->T));
+            hipLaunchKernelGGL(cpm::k_pdrive_mean, grid, dim3(64), 0, c->stream, c->d_dm, c->d_dist, c->d_pdrive_mean, static_cast<int>(c->Z));
+        }
         HIP_TRY(hipGetLastError());
         c->pdrive_mean_valid = true;
     }
@@ -1081,6 +1262,19 @@ int32_t cpm_build_p_dest(cpm_ctx *c, double e_dest, int32_t e_is_integer, double
     }
     if (!c->have_dmat) return fail(CPM_ERR_STATE, "build_p_dest: datamatrix first (cpm_set_datamatrix or cpm_createdatamatrix_*)");
     size_t bytes = sizeof(double) * c->Z * c->Z * c->T;
+    {   // a sparse datamatrix: everything from its compact rows (cpm_dataset.h); p_destin itself only when the caller wants the array
+        bool done = false;
+        int32_t rc_sp = build_p_dest_sparse(c, e_dest, e_is_integer, &done);
+        if (rc_sp != CPM_OK) return rc_sp;
+        if (done) {
+            if (!out) return CPM_OK;
+            rc_sp = ensure_dense_p(c);
+            if (rc_sp != CPM_OK) return rc_sp;
+            HIP_TRY(hipMemcpyAsync(out, c->d_p, bytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return CPM_OK;
+        }
+    }
     // createpdestin's array in the reference's layout: weights, then normalised in place.  It stays with the context (a sweep calls
     // this entry once per e_dest value: no allocation on that path); the row tables are derived from it in one more pass.
     if (!c->d_p) HIP_TRY(hipMalloc(&c->d_p, bytes));
@@ -1169,6 +1363,7 @@ int32_t cpm_synth_datamatrix(cpm_ctx *c, uint64_t table_seed, double density)
     c->have_dmat = c->have_dist = false;
     c->tt_valid = false;
     c->tts_valid = false;
+    c->ds_valid = false;
     c->pdrive_mean_valid = false;
     hipLaunchKernelGGL(cpm::k_synth_datamatrix, dim3(nblk(c->Z, 256), static_cast<unsigned>(c->Z), static_cast<unsigned>(c->T)), dim3(256), 0, c->stream,
                        c->d_dm, static_cast<int>(c->Z), static_cast<int>(c->T), table_seed, density);
@@ -1187,7 +1382,15 @@ int32_t cpm_refresh_tables(cpm_ctx *c, int32_t with_f64_cdf)
         int32_t rc_ivp = finish_ivp(c);
         if (rc_ivp != CPM_OK) return rc_ivp;
     }
-    if (!c->have_cdf || !c->d_p) return fail(CPM_ERR_STATE, "refresh_tables: p_dest not set");
+    if (!c->have_cdf) return fail(CPM_ERR_STATE, "refresh_tables: p_dest not set");
+    if (c->sparse_tables) {  // (the tables of a compact dataset: its rows are what they are rebuilt from)
+        if (!c->ds_valid || !c->ds_ok) return fail(CPM_ERR_STATE, "refresh_tables: the datamatrix these tables were built from has been replaced");
+        bool done = false;
+        int32_t rc_sp = build_p_dest_sparse(c, c->tab_e_dest, c->tab_e_int, &done);
+        if (rc_sp != CPM_OK || !done) return rc_sp != CPM_OK ? rc_sp : fail(CPM_ERR_STATE, "refresh_tables: compact rows no longer usable");
+        return with_f64_cdf ? ensure_full_cdf(c) : CPM_OK;
+    }
+    if (!c->d_p) return fail(CPM_ERR_STATE, "refresh_tables: p_dest not set");
     return build_rows(c, with_f64_cdf != 0);
 }
 
@@ -1389,7 +1592,7 @@ int32_t cpm_algorithmic_bytes_per_hour(cpm_ctx *c, int64_t *bytes_out)
     // The second-generation grouped path streams the 4-byte high-word rows (Zq per row) instead of the f64 rows:
     // its true element size is substituted, as 8(d) prescribes for a variant with a different element size.
     const bool hi_rows = pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && grouped_fits(c, c->zg.cap_mult);
-    const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(cpm::pack_row_words(c->Zq, cpm::pack_guide_bits(static_cast<int>(c->Z)))) * 4 + c->Z * 8
+    const int64_t rows = hi_rows ? c->Z * static_cast<int64_t>(cpm::pack_row_words(c->Zq, c->pk_G, c->sparse_tables)) * 4 + c->Z * 8
                                  : c->Z * c->Z * 8;
     *bytes_out = rows + c->Z * 8 + c->n * 8 + 2 * c->Z * 8;
     return CPM_OK;
@@ -1414,15 +1617,24 @@ int32_t cpm_debug_categorical(cpm_ctx *c, int64_t origin1, int64_t hour1, int64_
     if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(int), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, k53, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        const int G = cpm::pack_guide_bits(static_cast<int>(c->Z));
-        const size_t words = static_cast<size_t>(cpm::pack_row_words(c->Zq, G));
+        const int G = c->pk_G;
+        const size_t words = static_cast<size_t>(cpm::pack_row_words(c->Zq, G, c->sparse_tables));
         const size_t lds = sizeof(uint32_t) * words;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cpm::k_pack_search_debug), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         const size_t th = static_cast<size_t>(hour1 - 1);
-        hipLaunchKernelGGL(cpm::k_pack_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
-                           c->d_ckpt + th * cpm::ckpt_count(static_cast<int>(c->Z)) * c->Z, c->d_p + th * c->Z * c->Z,
-                           static_cast<int>(origin1 - 1), static_cast<int>(c->Z), c->Zq, G, n, d_k, d_o, d_n);
+        uint32_t h_scnt = 0;
+        if (c->sparse_tables) {
+            e = hipMemcpyAsync(&h_scnt, c->d_scnt + row, sizeof h_scnt, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (e == hipSuccess) {
+            const bool sp = c->sparse_tables;
+            hipLaunchKernelGGL(cpm::k_pack_search_debug, dim3(1), dim3(512), lds, c->stream, c->d_hi + row * words, c->d_last + row,
+                               sp ? nullptr : c->d_ckpt + th * cpm::ckpt_count(static_cast<int>(c->Z)) * c->Z, sp ? nullptr : c->d_p + th * c->Z * c->Z,
+                               static_cast<int>(origin1 - 1), static_cast<int>(c->Z), c->Zq, G, c->pk_Zc, sp ? c->d_sp + row * cpm::kDsCap : nullptr,
+                               sp ? c->d_sj + row * cpm::kDsCap : nullptr, std::min(h_scnt, cpm::kDsCap), n, d_k, d_o, d_n);
+        }
         e = hipGetLastError();
     }
     int h_n = 0;

@@ -66,11 +66,10 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
     uint32_t &s_nstay = sl.nstay, &s_bcast = sl.pad_, &s_ready = sl.ndrive;
     uint32_t(&gb)[kGroups] = sl.gb;
     uint32_t(&stage)[kGroups * kStage] = sl.stage;
-    const int Z = a.Z;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     const uint32_t myx = xcc_id();
@@ -129,6 +128,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
+    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
     uint32_t hi_last = 0;
     const CarIndex cars = a.cars;
     const uint32_t top4 = (cap - 1u) << 2;
@@ -218,10 +218,10 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
             if (ph == 0) {  // every wave's pieces of the pack have landed (its own: waited for above)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                hi_last = hi[Z - 1];
+                hi_last = hi[a.Zc - 1];
             }
             if constexpr (K > 0) {
-                pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+                pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok, smap);
                 bool anyx = false;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
             car_draw_words(a.seed, cars.global(idx), a.step, kb, clo1[0], khi1[0]);
             const bool drive1 = valid1 & (kb <= thr);
             want1[0] = drive1 & (last != 0.0);
-            pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
+            pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1, smap);
             if (!want1[0]) dest1[0] = z;
             else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
             const unsigned long long m1 = ballot64(valid1 & !drive1);
@@ -478,9 +478,9 @@ __device__ __forceinline__ void day_fill_hour(const GroupedDay &d, int t, Groupe
 
 
 template <int CPT, int NQ>
-inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, int G, int gshift, int nchunk, int mix, hipStream_t stream)
+inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
 {
-    const size_t lds = fused_lds_bytes(Zq, G);
+    const size_t lds = fused_lds_bytes(Zq, G, smap);
     if (lds > 48 * 1024) {
         static bool attr_done[64] = {};
         int dev = 0;
@@ -494,10 +494,10 @@ inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, 
     launch(k_grouped_day<CPT, NQ>, dim3(static_cast<unsigned>(nhours) * static_cast<unsigned>(per_hour)), dim3(kFusedThreads), lds, stream, hours, per_hour, nchunk, mix);
 }
 template <int CPT>
-inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, int G, int gshift, int nchunk, int mix, hipStream_t stream)
+inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
 {
-    const int need = (pack_row_words(Zq, G) / 4 + kSampleBlock - 1) / kSampleBlock;
-#define CPM_DAY_ARGS hours, nhours, Zq, G, gshift, nchunk, mix, stream
+    const int need = (pack_row_words(Zq, G, smap) / 4 + kSampleBlock - 1) / kSampleBlock;
+#define CPM_DAY_ARGS hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream
     if (need <= 1) grouped_launch_day_nq<CPT, 1>(CPM_DAY_ARGS);
     else if (need <= 2) grouped_launch_day_nq<CPT, 2>(CPM_DAY_ARGS);
     else if (need <= 3) grouped_launch_day_nq<CPT, 3>(CPM_DAY_ARGS);
@@ -508,13 +508,13 @@ inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, i
     else grouped_launch_day_nq<CPT, 12>(CPM_DAY_ARGS);
 #undef CPM_DAY_ARGS
 }
-inline void grouped_launch_day(const GroupedArgs *hours, int nhours, int Z, int Zq, int G, int gshift, int nchunk, int mix, int64_t mean, hipStream_t stream)
+inline void grouped_launch_day(const GroupedArgs *hours, int nhours, int Z, int Zq, int G, int smap, int gshift, int nchunk, int mix, int64_t mean, hipStream_t stream)
 {
     (void)Z;
     switch (grouped_cpt(mean)) {
-    case 1: grouped_launch_day_c<1>(hours, nhours, Zq, G, gshift, nchunk, mix, stream); break;
-    case 2: grouped_launch_day_c<2>(hours, nhours, Zq, G, gshift, nchunk, mix, stream); break;
-    default: grouped_launch_day_c<4>(hours, nhours, Zq, G, gshift, nchunk, mix, stream); break;
+    case 1: grouped_launch_day_c<1>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
+    case 2: grouped_launch_day_c<2>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
+    default: grouped_launch_day_c<4>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
     }
 }
 

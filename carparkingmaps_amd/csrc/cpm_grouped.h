@@ -77,10 +77,11 @@ __host__ __device__ inline int pack_guide_bits(int Z)
 // its bracket), a whole number of 128-B lines
 __host__ __device__ inline int pack_zq(int Z) { return (Z + 31 + 31) / 32 * 32; }
 __host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4; }  // 2^G + 1 entries used (+7 pad: whole 16-B pieces)
-__host__ __device__ inline int pack_row_words(int Zq, int G)  // at least 1 KiB: one whole LDS-DMA wave-instruction
+// smap (sparse pack, cpm_dataset.h): Zq and G of the compact row, and a u16 destination per entry behind the high words
+__host__ __device__ inline int pack_row_words(int Zq, int G, int smap = 0)  // at least 1 KiB: one whole LDS-DMA wave-instruction
 {
-    const int w = pack_guide_words(G) + Zq;
-    return w < 256 ? 256 : w;
+    const int w = pack_guide_words(G) + Zq + (smap ? Zq / 2 : 0);  // (Zq is a multiple of 32)
+    return w < 256 ? 256 : (w + 3) / 4 * 4;
 }
 // a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
 inline bool pack_row_fits(int Z)
@@ -188,7 +189,11 @@ __global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__r
 // and read back with v_readlane in its hot paths), and nine more pointers in its arguments cost it 6 us per launch.  Written by
 // k_grouped_zero at the start of every run.
 struct GroupedRare {
-    const double *ckpt, *p;               // [T][nck][Z] running-sum checkpoints, [T][Z dest][Z origin] p_destin
+    const double *ckpt, *p;               // [T][nck][Z] running-sum checkpoints, [T][Z dest][Z origin] p_destin (dense tables)
+    const double *sp;                     // sparse tables (cpm_dataset.h): [T*Z][scap] normalised p of every row's cells, in destination order; else null
+    const uint32_t *sj;                   // ... their destinations
+    const uint32_t *scnt;                 // ... [T*Z] cells per row
+    uint32_t scap, pad0_;
     uint32_t *maxn, *heavy_list, *nheavy; // [2] largest heavy bucket / most heavy buckets of an hour; [hgrid] zones of this hour's heavy launch; [T+1] how many per hour
     unsigned long long *status;           // the status word of the run's count tensor
     uint32_t hgrid, parts;                // zones the heavy launch covers, workgroups per heavy zone (GroupedWork)
@@ -208,7 +213,9 @@ struct GroupedArgs {
     uint32_t *D;              // [Z][kGroups][scap] packed drivers (grouped)
     uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
     unsigned long long *parking_t, *driving_t;
-    int Z, Zq, G;
+    int Z, Zq, G;             // (sparse packs, cpm_dataset.h: Zq and G of the COMPACT row)
+    int Zc;                   // entries of a pack row in front of its 0xFFFFFFFF pad: Z, or the longest compact row of a sparse table
+    int smap;                 // 1: sparse pack -- the search's answer is an entry, its destination stands in the u16 map behind the high words
     int hour;                 // table hour of this launch (0-based): rare->nheavy[hour] counts its heavy buckets
     uint32_t *done_t;         // fused hour: [chunks] sampler workgroups of every chunk of origin zones that have handed their runs over
     int lag;                  // fused hour: the placing blocks of chunk j sit behind the sampler workgroups of chunk j + lag
@@ -544,11 +551,28 @@ __device__ __forceinline__ uint32_t search_exact_tables(const double *__restrict
     return static_cast<uint32_t>(Z - 1);
 }
 
+// ... on a sparse table: the same walk over the row's cells in destination order (the zeros in between add nothing: every partial
+// sum equals the dense row's there), from the row's first cell (at most scap cells; a tie is a 2^-32 event per cell)
+__device__ __forceinline__ uint32_t search_exact_sparse(const double *__restrict__ sp, const uint32_t *__restrict__ sj, uint32_t n, double uc, double last)
+{
+    const double ue = clamp_u(uc, last);
+    double run = 0.0;
+    for (uint32_t e = 0; e < n; ++e) {
+        run = run + sp[e];
+        if (run >= ue) return sj[e];
+    }
+    return n ? sj[n - 1] : 0u;
+}
+
 // the exact fallback of one car of the hourly kernels (rare: out of line, reads its tables through the rare block)
 __device__ __noinline__ uint32_t search_exact_ckpt(const GroupedRare *__restrict__ rare, int hour, int o, double uc, double last, int hint)
 {
     const int Z = rare->Z;
     const size_t th = static_cast<size_t>(hour);
+    if (rare->sp) {
+        const size_t row = th * Z + o;
+        return search_exact_sparse(rare->sp + row * rare->scap, rare->sj + row * rare->scap, min(rare->scnt[row], rare->scap), uc, last);
+    }
     return search_exact_tables(rare->ckpt + th * ckpt_count(Z) * Z, rare->p + th * Z * Z, Z, o, uc, last, hint);
 }
 
@@ -598,10 +622,13 @@ __device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
 // highest one below the draw wins -- shortened the dependent chain and lengthened the launch, 27.5 us against 26.8: the kernel is
 // bound by what it issues, not by this latency; profiles/round2_notes.md.)  Brackets of 32 entries and more (rows with long runs of
 // zero-probability zones) take the same walk from a larger K with the probe index clamped to the row.
+// smap != null (sparse pack, cpm_dataset.h): the row is the COMPACT row of the destinations that hold weight; the entry found is mapped
+// to its destination at the end (one more LDS read per draw; wave-uniform branch).
 template <int CPT>
 __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint32_t *hi_g, const uint32_t (&khi)[CPT], const bool (&want)[CPT],
-                                            int sh, uint32_t hi_last, int Zq, uint32_t (&dest)[CPT], bool (&ok)[CPT])
+                                            int sh, uint32_t hi_last, int Zq, uint32_t (&dest)[CPT], bool (&ok)[CPT], const uint16_t *smap_g = nullptr)
 {
+    lds_cu16 *smap = (lds_cu16 *)smap_g;
     lds_cu16 *guide = (lds_cu16 *)guide_g;
     lds_cu32 *hi = (lds_cu32 *)hi_g;
     uint32_t kk[CPT], lo[CPT], n[CPT], nor = 0;
@@ -635,6 +662,10 @@ __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint3
             dest[c] = lo[c];
             ok[c] = in[c] & (hi[lo[c]] > kk[c]);
         }
+        if (smap_g) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) dest[c] = smap[dest[c]];
+        }
         return;
     }
     lds_cu32 *p[CPT];
@@ -659,6 +690,10 @@ __device__ __forceinline__ void pack_search(const uint16_t *guide_g, const uint3
         const uint32_t fin = p[c][0];
         dest[c] = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p[c])) - static_cast<uint32_t>(reinterpret_cast<uintptr_t>(hi))) >> 2;
         ok[c] = in[c] & (fin > kk[c]);
+    }
+    if (smap_g) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) dest[c] = smap[dest[c]];
     }
 }
 
@@ -801,11 +836,10 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     uint32_t &s_ndrive = sl.ndrive, &s_nstay = sl.nstay, &s_split = sl.split;
     uint32_t(&gb)[kGroups] = sl.gb;
     uint32_t(&stage)[kGroups * kStage] = sl.stage;
-    const int Z = a.Z;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
     // Scalar loads first, then the id loads -- written in assembly and waited for by hand: with LDS-DMA in flight hipcc
     // (ROCm 7.2) drains vmcnt to 0 at the first use of any ordinary vector load result, which would put Philox behind the whole
     // pack.  The wave issues CPT + 1 id loads, then exactly NQ LDS-DMA instructions; vmcnt retires in order, so vmcnt <= NQ
@@ -937,6 +971,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     uint32_t *runs = GROUPED ? a.D + static_cast<size_t>(z) * kGroups * a.scap : nullptr;
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
+    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
     uint32_t hi_last = 0;
     auto first_pass = [&](auto kc) {
         constexpr int K = decltype(kc)::value;
@@ -958,9 +993,9 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         __syncthreads();
         CPM_SSTAMP(3);
         n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
-        hi_last = hi[Z - 1];
+        hi_last = hi[a.Zc - 1];
         if constexpr (K > 0) {
-            pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+            pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok, smap);
             {
                 bool anyx = false;
 #pragma unroll
@@ -1050,7 +1085,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         car_draw_words(a.seed, car, a.step, kb, clo1[0], khi1[0]);
         const bool drive1 = valid1 & (kb <= thr);
         want1[0] = drive1 & (last != 0.0);
-        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1);
+        pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1, smap);
         if (!want1[0]) dest1[0] = z;
         else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
         if (GROUPED) {
@@ -1140,7 +1175,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     extern __shared__ uint32_t pack[];
     __shared__ uint32_t gb[kGroups], gbase[kGroups];
     __shared__ uint32_t s_stay, s_sbase, s_nd;  // the block's stayers (sum of its waves'), their first slot in the bucket, its drivers
-    const int Z = a.Z;
     const GroupedRare *rare = a.rare;
     if (blockIdx.x >= min(rare->nheavy[a.hour], rare->hgrid)) return;  // (the list of this hour is shorter than the grid)
     const uint32_t item = rare->heavy_list[blockIdx.x];                 // one work item = one chunk of one listed zone
@@ -1156,7 +1190,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const uint32_t start0 = L * (1u + q);
     if (start0 >= n) return;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
@@ -1169,7 +1203,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     __syncthreads();
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
-    const uint32_t hi_last = hi[Z - 1];
+    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
+    const uint32_t hi_last = hi[a.Zc - 1];
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
@@ -1191,7 +1226,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
             drive[c] = valid[c] & (kb <= thr);
             want[c] = drive[c] & (last != 0.0);
         }
-        pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok);
+        pack_search<CPT>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok, smap);
         bool anyx = false;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
@@ -1921,7 +1956,8 @@ __global__ __launch_bounds__(64) void k_tts_cells(const double *__restrict__ dm,
 struct TravelArgs {
     const double2 *tt;            // [T][Z][Z] (mean, std), origin-major
     const uint2 *tts_words;       // sparse rows (k_tts_*): [T*Z][W] (bitmap, cells in front), or null: gather from tt
-    const uint32_t *tts_off;      // [T*Z + 1] first cell of every row
+    const uint32_t *tts_off;      // [T*Z + 1] first cell of every row -- or, fixed-stride rows (tts_stride != 0, cpm_dataset.h): [T*Z] cells per row
+    uint32_t tts_stride;          // ... the row's cells start at row * tts_stride
     const double2 *tts_cells;     // the non-zero cells, row by row: (mean, 1 / (2 sigma^2))
     int W;                        // bitmap words per row
     uint32_t list_off;            // sparse rows: byte offset of the threads' driver lists in the block's LDS (behind the largest row)
@@ -1954,7 +1990,8 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     double2 *row_cells = reinterpret_cast<double2 *>(travel_lds + ((static_cast<size_t>(tr.W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)));
     if constexpr (SPARSE) {  // (requested first: lands under the prefix scan of the run lengths)
         const size_t row = static_cast<size_t>(hour) * Z + z;
-        const uint32_t c0 = tr.tts_off[row], nc = tr.tts_off[row + 1] - c0;
+        const size_t c0 = tr.tts_stride ? row * tr.tts_stride : tr.tts_off[row];
+        const uint32_t nc = tr.tts_stride ? min(tr.tts_off[row], tr.tts_stride) : tr.tts_off[row + 1] - tr.tts_off[row];
         for (int i = tid; i < tr.W; i += blockDim.x) row_words[i] = tr.tts_words[row * tr.W + i];
         for (uint32_t i = tid; i < nc; i += blockDim.x) row_cells[i] = tr.tts_cells[c0 + i];
     }
@@ -2124,7 +2161,7 @@ inline void grouped_launch_nq(const GroupedArgs &a, size_t lds, hipStream_t stre
 template <bool GROUPED, int CPT>
 inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
 {
-    const int words = pack_row_words(a.Zq, a.G);
+    const int words = pack_row_words(a.Zq, a.G, a.smap);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
     if (need <= 1) grouped_launch_nq<GROUPED, CPT, 1>(a, lds, stream);
@@ -2142,14 +2179,14 @@ inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
 inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2 : 4); }
 
 // the fused hour (k_grouped_hour): (chunks + lag) x (kFusedChunk sampler workgroups + kGroups placing blocks)
-inline size_t fused_lds_bytes(int Zq, int G)
+inline size_t fused_lds_bytes(int Zq, int G, int smap = 0)
 {
-    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G)), static_cast<size_t>(4 + sizeof(PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg>::zone_t)) * kFusedKruns * kFusedKdeep * kFusedThreads);
+    return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G, smap)), static_cast<size_t>(4 + sizeof(PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg>::zone_t)) * kFusedKruns * kFusedKdeep * kFusedThreads);
 }
 template <int CPT, int NQ>
 inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
 {
-    const size_t lds = fused_lds_bytes(a.Zq, a.G);
+    const size_t lds = fused_lds_bytes(a.Zq, a.G, a.smap);
     if (lds > 48 * 1024) {
         static bool attr_done[64] = {};
         int dev = 0;
@@ -2165,9 +2202,9 @@ inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
     launch(k_grouped_hour<CPT, NQ>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
 }
 // true when an instantiation exists for this problem (the common pack sizes; others take two launches per hour)
-inline bool fused_shape_ok(int Z, int Zq, int G)
+inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
 {
-    const int need = (pack_row_words(Zq, G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    const int need = (pack_row_words(Zq, G, smap) / 4 + kSampleBlock - 1) / kSampleBlock;
     return (1 << grouped_gshift_of(Z)) <= kFusedZpg && need <= 12;
 }
 // ... and where it PAYS.  MEASURED (one launch against two per hour, 1,000 cars per zone, interleaved runs on one box, ms per
@@ -2175,15 +2212,15 @@ inline bool fused_shape_ok(int Z, int Zq, int G)
 // 0.760, 2,000: 2.21 / 2.21), 5,120: 1.283 / 1.362, 6,144: 1.680 / 1.615, 8,192 x 500: 2.19 / 2.07.  It pays from two rounds of sampler
 // workgroups on (12 per CU) while the blocks' LDS -- every block of the fused launch carries the row pack's -- leaves five per
 // CU: below, the one launch has no second round to tuck its placing blocks behind; above, the placing blocks sit four to a CU.
-inline bool fused_pays(int Z, int Zq, int G, int cu_count)
+inline bool fused_pays(int Z, int Zq, int G, int cu_count, int smap = 0)
 {
-    const size_t lds = fused_lds_bytes(Zq, G) + 4608;  // (+ the static part: SampleLds / PlaceLds)
+    const size_t lds = fused_lds_bytes(Zq, G, smap) + 4608;  // (+ the static part: SampleLds / PlaceLds)
     return Z >= 12 * std::max(cu_count, 1) && 5 * lds <= 160 * 1024;
 }
 template <int CPT>
 inline void grouped_launch_hour_c(const GroupedArgs &a, hipStream_t stream)
 {
-    const int need = (pack_row_words(a.Zq, a.G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    const int need = (pack_row_words(a.Zq, a.G, a.smap) / 4 + kSampleBlock - 1) / kSampleBlock;
     if (need <= 1) grouped_launch_hour_nq<CPT, 1>(a, stream);
     else if (need <= 2) grouped_launch_hour_nq<CPT, 2>(a, stream);
     else if (need <= 3) grouped_launch_hour_nq<CPT, 3>(a, stream);
@@ -2205,7 +2242,7 @@ inline void grouped_launch_hour(const GroupedArgs &a, int64_t mean, hipStream_t 
 template <int CPT, int NQ, bool GROUPED>
 inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
 {
-    const size_t lds = fused_lds_bytes(a.Zq, a.G);
+    const size_t lds = fused_lds_bytes(a.Zq, a.G, a.smap);
     if (lds > 48 * 1024) {
         static bool attr_done[64] = {};
         int dev = 0;
@@ -2220,7 +2257,7 @@ inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
 template <int CPT, bool GROUPED>
 inline void grouped_launch_hour_pf_c(const GroupedArgs &a, hipStream_t stream)
 {
-    const int need = (pack_row_words(a.Zq, a.G) / 4 + kSampleBlock - 1) / kSampleBlock;
+    const int need = (pack_row_words(a.Zq, a.G, a.smap) / 4 + kSampleBlock - 1) / kSampleBlock;
     if (need <= 1) grouped_launch_hour_pf_nq<CPT, 1, GROUPED>(a, stream);
     else if (need <= 2) grouped_launch_hour_pf_nq<CPT, 2, GROUPED>(a, stream);
     else if (need <= 3) grouped_launch_hour_pf_nq<CPT, 3, GROUPED>(a, stream);
@@ -2259,7 +2296,7 @@ inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, 
 template <int CPT>
 inline void grouped_launch_heavy_c(const GroupedArgs &a, int parts, int hgrid, hipStream_t stream)
 {
-    const int words = pack_row_words(a.Zq, a.G);
+    const int words = pack_row_words(a.Zq, a.G, a.smap);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
     if (need <= 2) grouped_launch_heavy_nq<CPT, 2>(a, parts, hgrid, lds, stream);
@@ -2293,14 +2330,15 @@ inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_
 
 // Diagnostic (cpm_debug_categorical): the categorical draw of the sampler for given 53-bit draws k against one
 // installed row, through the same staging, search and exact-row code.  out[i] = destination (1-based), or 0 for a zero row.
+// sparse tables (sp != null): Zq, G, Zc of the compact row, the row's normalised cells for the ties
 __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__restrict__ pack_g, const double *__restrict__ last_p,
                                                            const double *__restrict__ ckpt_t, const double *__restrict__ p_t, int origin, int Z, int Zq,
-                                                           int G, int64_t n,
-                                                           const uint64_t *__restrict__ k53, int64_t *__restrict__ out, int *__restrict__ n_exact)
+                                                           int G, int Zc, const double *__restrict__ sp, const uint32_t *__restrict__ sj, uint32_t scnt,
+                                                           int64_t n, const uint64_t *__restrict__ k53, int64_t *__restrict__ out, int *__restrict__ n_exact)
 {
     extern __shared__ uint32_t pack[];
     const int tid = threadIdx.x;
-    const int gw = pack_guide_words(G), pieces = pack_row_words(Zq, G) / 4, sh = 32 - G;
+    const int gw = pack_guide_words(G), pieces = pack_row_words(Zq, G, sp ? 1 : 0) / 4, sh = 32 - G;
     {
         const int lane = tid & 63;
         for (int p0 = tid - lane; p0 < pieces; p0 += 512) {  // wave-uniform trips
@@ -2315,7 +2353,8 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
     const double last = *last_p;
-    const uint32_t hi_last = hi[Z - 1];
+    const uint32_t hi_last = hi[Zc - 1];
+    const uint16_t *smap = sp ? reinterpret_cast<const uint16_t *>(hi + Zq) : nullptr;
     for (int64_t i0 = 0; i0 < n; i0 += 512) {  // wave-uniform trips (pack_search votes across the wave)
         const int64_t i = i0 + tid;
         const bool live = i < n;
@@ -2324,14 +2363,15 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
         bool ok[1];
         const uint32_t khi[1] = {static_cast<uint32_t>(k >> 21)};
         const bool want[1] = {live && last != 0.0};
-        pack_search<1>(guide, hi, khi, want, sh, hi_last, Zq, dest, ok);
+        pack_search<1>(guide, hi, khi, want, sh, hi_last, Zq, dest, ok, smap);
         if (!live) continue;
         if (last == 0.0) {
             out[i] = 0;
             continue;
         }
         if (!ok[0]) {
-            dest[0] = search_exact_tables(ckpt_t, p_t, Z, origin, static_cast<double>(k) * 0x1.0p-53, last, khi[0] <= hi_last ? static_cast<int>(dest[0]) : -1);
+            if (sp) dest[0] = search_exact_sparse(sp, sj, scnt, static_cast<double>(k) * 0x1.0p-53, last);
+            else dest[0] = search_exact_tables(ckpt_t, p_t, Z, origin, static_cast<double>(k) * 0x1.0p-53, last, khi[0] <= hi_last ? static_cast<int>(dest[0]) : -1);
             atomicAdd(n_exact, 1);
         }
         out[i] = static_cast<int64_t>(dest[0]) + 1;
@@ -2502,7 +2542,14 @@ struct GroupedTables {
     const double2 *tts_cells = nullptr;
     int tts_W = 0;
     size_t tts_lds = 0;      // bytes of the largest row (words + cells)
+    const uint32_t *tts_cnt = nullptr;  // fixed-stride travel rows (cpm_dataset.h): cells per row; the row's cells start at row * tts_stride
+    uint32_t tts_stride = 0;
     int Z, Zp, Zq, T;
+    int G = 0, Zc = 0, smap = 0;        // pack geometry: guide bits, entries in front of the pad, sparse packs (cpm_dataset.h: Zq, G, Zc of the compact row)
+    const double *sp = nullptr;         // sparse tables: the rows' normalised cells / cells / counts (what a tie walks)
+    const uint32_t *sj = nullptr;
+    const uint32_t *scnt = nullptr;
+    uint32_t scap = 0;
 };
 
 // Everything a run starts from zero, in ONE launch: the count tensor (driving counts, time sum and status word are added to),
@@ -2554,12 +2601,12 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     unsigned long long *status = tt_sum + 1;
     // travel times: from the runs, by one launch per hour -- or, when the runs of all hours fit, by one launch at the end
     const bool history = travel && !ivp && w.ensure_history();
-    const int G = pack_guide_bits(Z);
-    const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G));
+    const int G = tb.G;
+    const size_t rw = static_cast<size_t>(pack_row_words(tb.Zq, G, tb.smap));
     const int64_t mean = (n + Z - 1) / Z;
     const int hours = ivp ? T - 1 : T;
     // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
-    const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count));
+    const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G, tb.smap) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count, tb.smap));
     // ... and one launch for ALL hours that are applied (k_grouped_day): the IVP's T - 1, a resample's first T - 1 (hour T is sampled,
     // never applied: the plain form behind the placing of hour T - 1, k_grouped_hour_pf); hourly travel launches need hourly boundaries
     const int day_n = (shape && w.fused_day && w.cap < (1u << kCntXccShift) && (!travel || history)) ? (ivp ? hours : hours - 1) : 0;
@@ -2570,6 +2617,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.Z = Z;
         a.Zq = tb.Zq;
         a.G = G;
+        a.Zc = tb.Zc;
+        a.smap = tb.smap;
         a.cap = w.cap;
         a.scap = w.scap;
         a.idbits = w.idbits;
@@ -2616,6 +2665,10 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         GroupedRare rn{};
         rn.ckpt = tb.ckpt;
         rn.p = tb.p;
+        rn.sp = tb.sp;
+        rn.sj = tb.sj;
+        rn.scnt = tb.scnt;
+        rn.scap = tb.scap;
         rn.maxn = w.maxn;
         rn.heavy_list = w.heavy_list;
         rn.nheavy = w.nheavy;
@@ -2646,7 +2699,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     int t_first = 0;
     if (day_n >= 2) {
         prof_begin(CPM_PROFILE_SAMPLER);
-        grouped_launch_day(w.day_hours, day_n, Z, tb.Zq, G, static_cast<int>(w.gshift), nchunk, w.day_mix, mean, stream);
+        grouped_launch_day(w.day_hours, day_n, Z, tb.Zq, G, tb.smap, static_cast<int>(w.gshift), nchunk, w.day_mix, mean, stream);
         prof_end(CPM_PROFILE_SAMPLER);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone day launch");
         // the drivers of its last hour are still in their runs: placed in front of hour T's sampler workgroups, or by a launch of their own
@@ -2715,7 +2768,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             TravelArgs tr{};
             tr.tt = tb.tt;
             tr.tts_words = tb.tts_words;
-            tr.tts_off = tb.tts_off;
+            tr.tts_off = tb.tts_stride ? tb.tts_cnt : tb.tts_off;
+            tr.tts_stride = tb.tts_stride;
             tr.tts_cells = tb.tts_cells;
             tr.W = tb.tts_W;
             tr.tt_part = w.tt_part;
@@ -2737,7 +2791,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         TravelArgs tr{};
         tr.tt = tb.tt;
         tr.tts_words = tb.tts_words;
-        tr.tts_off = tb.tts_off;
+        tr.tts_off = tb.tts_stride ? tb.tts_cnt : tb.tts_off;
+        tr.tts_stride = tb.tts_stride;
         tr.tts_cells = tb.tts_cells;
         tr.W = tb.tts_W;
         tr.tt_part = w.tt_part;

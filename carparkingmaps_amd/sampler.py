@@ -72,7 +72,9 @@ class Sampler:
             _lib.check(self._L.cpm_set_option(self._h, _lib.CPM_OPT_FUSED_LAG, int(lag)))
 
     def get_info(self, what):
-        """cpm_get_info: 1 = kernel family AUTO resolves to now, 2 = bucket-region size in multiples of the mean bucket."""
+        """cpm_get_info: 1 = kernel family AUTO resolves to now, 2 = bucket-region size in multiples of the mean bucket, 3 = workgroups per
+        heavy zone, 4 = form of the hour (0 two launches, 1 one, 3 placing first, 6 all hours in one launch), 5 = steps that bailed out of a
+        one-launch form, 6 = words of a sparse row pack (0: dense tables)."""
         v = C.c_int64(0)
         _lib.check(self._L.cpm_get_info(self._h, int(what), C.byref(v)))
         return int(v.value)
@@ -160,7 +162,8 @@ class Sampler:
         _lib.check(self._L.cpm_synth_datamatrix(self._h, int(table_seed), float(density)))
 
     def refresh_tables(self, with_f64_cdf=False):
-        """Re-derive the row tables from the resident p_destin (the one pass the installing calls end in); for measurement."""
+        """Re-derive the row tables from the resident p_destin -- or from the compact rows of the dataset they were built from -- (the one
+        pass the installing calls end in); for measurement."""
         _lib.check(self._L.cpm_refresh_tables(self._h, 1 if with_f64_cdf else 0))
 
     def get_p_drive(self):

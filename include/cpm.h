@@ -108,6 +108,9 @@ int32_t cpm_set_option(cpm_ctx *ctx, int32_t option, int64_t value);
 #define CPM_INFO_CAP_MULT 2
 #define CPM_INFO_PARTS 3   /* workgroups per zone of the grouped sampler: 1, or more once a bucket above FOUR times a workgroup's slots was seen
                             * (kHeavy in cpm_grouped.h; lighter overflow stays with the overflow rounds of the zone's own workgroup) */
+#define CPM_INFO_SPARSE_TABLES 6  /* 0, or -- the installed p_destin tables were built from a sparse datamatrix's compact rows (csrc/cpm_dataset.h:
+                                   * cpm_build_p_dest on a datamatrix whose longest (origin, hour) row holds at most 512 cells and whose sparse
+                                   * row pack is at most 60 % of the dense one) -- the 32-bit words of one sparse row pack */
 #define CPM_INFO_FUSED_BAILOUTS 5 /* steps so far that came back with status bit 2 (a block of a one-launch form gave up waiting: the context then keeps to two launches per hour) */
 #define CPM_INFO_FUSED 4   /* 1 (3: in its placing-first form, 6: all hours in one launch) when the next grouped step runs the fused hour (one launch per hour), 0 when it takes two launches per hour: switched
                             * off (CPM_OPT_FUSED), heavy buckets seen (CPM_INFO_PARTS > 1), rows / groups outside the fused instantiations, or

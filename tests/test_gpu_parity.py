@@ -712,8 +712,8 @@ def test_high_word_search_equals_the_f64_search_on_ties_and_edges(cpm, O):
 
 
 def test_unnormalised_weights_and_row_sums_give_the_same_tables(cpm, O):
-    """cpm_build_p_dest without a host copy keeps createpdestin's WEIGHTS and their row sums on the device and divides where an
-    entry is read (k_build_rows, search_exact_ckpt) -- the CDF rows, the packs and the tie fallback must be those of the
+    """cpm_build_p_dest without a host copy (weights, sequential row sums, division in place: k_pdest_weights / _rowsum / _divide on a
+    datamatrix too dense for the compact-row builders) -- the CDF rows, the packs and the tie fallback must be those of the
     normalised table (src/createpdestin.jl:38-46 then src/resampling.jl:39).  Checked row by row against the oracle's
     createpdestin + sequential sum, with draws on, below and above every breakpoint (ties go through the checkpoint walk)."""
     Z, T = 333, 24
@@ -1130,3 +1130,66 @@ def test_randomized_small_configurations(cpm, O, seed):
             assert np.array_equal(s.solve_ivp(SIM_SEED + seed), ref["zone0"]), (kernel, Z, T, cpz)
             r = s.resample(SIM_SEED + seed)
             assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (kernel, Z, T, cpz)
+
+
+def test_sparse_dataset_tables_equal_the_dense_ones(cpm, O):
+    """A sparse datamatrix takes the compact-row builders (csrc/cpm_dataset.h: ONE sweep of the datamatrix, everything else on the 6 % of
+    the cells that hold data; sparse row packs in the sampler).  Against the oracle's dense createpdrive / createpdestin
+    (src/createpdrive.jl:10-33, src/createpdestin.jl:10-46) and its run on them: the tables a caller gets back, the f64 CDF rows built
+    on demand, the categorical draw on, below and above every breakpoint (ties walk the row's cells), the post-IVP state, counts and
+    travel-time sum -- for the Int exponent of main.jl:38 and a Float64 one, with an origin without data, a (mean 0, std > 0) cell
+    and Z not a multiple of 32."""
+    Z, T, cpz = 700, 24, 60
+    C = Z * cpz
+    dm, dist = O.synth_datamatrix(Z, T, TABLE_SEED, density=0.06)
+    dm[7, :, :, :] = 0.0                      # an origin without data: all-zero rows, p_drive = 0
+    dm[11, 13, 5, 0], dm[11, 13, 5, 1] = 0.0, 5.0   # a cell with a std and no mean: never a destination, but a cell of the travel row
+    dm = np.asfortranarray(dm)
+    rng = np.random.default_rng(6)
+    with cpm.Sampler(Z, T) as s:
+        s.set_datamatrix(dm, dist)
+        p_drive = s.build_p_drive(0.1, 0.9, 0.5)
+        np.testing.assert_allclose(p_drive, O.createpdrive(dm, dist, Z, T, 0.1, 0.9, 0.5), rtol=4e-16, atol=0, equal_nan=True)
+        for e_dest in (2, 0.5):
+            p_dest = s.build_p_dest(e_dest)
+            assert s.get_info(6) > 0                       # the sparse route was taken
+            want_p = O.createpdestin(dm, Z, T, e_dest)
+            if isinstance(e_dest, int):
+                assert np.array_equal(p_dest, want_p)
+            else:
+                np.testing.assert_allclose(p_dest, want_p, rtol=1e-12, atol=0)
+            s.build_p_dest(e_dest, want=False)             # (no dense array this time: the tables alone)
+            total_exact = 0
+            for (o, t) in [(1, 1), (8, 3), (Z, T), (100, 12), (12, 6)]:
+                cdf = np.cumsum(p_dest[o - 1, :, t - 1])
+                t53 = np.floor(np.minimum(cdf, 1.0 - 2.0 ** -53) * 2.0 ** 53).astype(np.int64)
+                k53 = np.concatenate([np.array([0, 1, 2 ** 53 - 1, 2 ** 21, 2 ** 21 - 1])] +
+                                     [np.clip(t53 + d, 0, 2 ** 53 - 1) for d in (-2 ** 21, -1, 0, 1, 2 ** 21)] +
+                                     [rng.integers(0, 2 ** 53, size=3000)]).astype(np.uint64)
+                got, n_exact = s.debug_categorical(o, t, k53)
+                assert np.array_equal(got, _ref_categorical(cdf, k53)), (e_dest, o, t)
+                total_exact += n_exact
+                assert np.array_equal(s.get_cdf_row(o, t), cdf), (o, t)   # (dense p_destin and its f64 rows, built on demand)
+            assert total_exact > 100
+            ref = O.fast_run(p_drive, O.build_cdf(p_dest), C, SIM_SEED, _zone0(C, cpz), datamatrix=dm, dist=dist)
+            for kernel in (0, 2, 5):
+                s.set_kernel(kernel)
+                s.init_states(C, cpz)
+                assert np.array_equal(s.solve_ivp(SIM_SEED), ref["zone0"]), (e_dest, kernel)
+                r = s.resample(SIM_SEED, travel=True)
+                assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (e_dest, kernel)
+                assert r["sum_tt_q16"] == ref["sum_tt_q16"], (e_dest, kernel)
+            s.set_kernel(0)
+            s.refresh_tables()
+            assert s.get_info(6) > 0
+            r = s.resample(SIM_SEED)
+            assert np.array_equal(r["parking"], ref["parking"])
+        # a new datamatrix behind installed sparse tables: they stay whole (a tie walks the TABLE's cells, not the new dataset's)
+        dm2, dist2 = O.synth_datamatrix(Z, T, TABLE_SEED + 1, density=0.06)
+        s.set_datamatrix(dm2, dist2)
+        s.build_p_drive(0.1, 0.9, 0.5, want=False)         # (sweeps the NEW datamatrix into the compact rows)
+        s.set_p_drive(p_drive)
+        cdf = np.cumsum(p_dest[99, :, 11])
+        t53 = np.floor(np.minimum(cdf, 1.0 - 2.0 ** -53) * 2.0 ** 53).astype(np.uint64)
+        got, n_exact = s.debug_categorical(100, 12, t53)
+        assert np.array_equal(got, _ref_categorical(cdf, t53)) and n_exact > 0
