@@ -91,7 +91,7 @@ struct cpm_ctx {
     // the same as sparse rows (cpm_grouped.h, k_tts_*), when the largest row fits LDS: what the travel kernel stages per (origin, hour)
     uint2 *d_tts_words = nullptr;
     uint32_t *d_tts_off = nullptr;
-    double2 *d_tts_cells = nullptr;
+    cpm::TravelCell *d_tts_cells = nullptr;
     size_t tts_cells_cap = 0, tts_lds = 0;
     bool tts_valid = false;
     bool tts_fixed = false;  // the travel rows are those of the compact dataset: fixed stride kDsCap, counts in d_ds_cnt
@@ -485,7 +485,7 @@ int32_t ensure_dataset(cpm_ctx *c)
     if (c->tts_cells_cap < static_cast<size_t>(rows) * cpm::kDsCap) {
         dfree(c->d_tts_cells);
         c->tts_cells_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(double2) * static_cast<size_t>(rows) * cpm::kDsCap));
+        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(cpm::TravelCell) * static_cast<size_t>(rows) * cpm::kDsCap));
         c->tts_cells_cap = static_cast<size_t>(rows) * cpm::kDsCap;
     }
     const size_t lds_sort = sizeof(uint32_t) * 2 * W * cpm::kDsRows;
@@ -494,7 +494,7 @@ int32_t ensure_dataset(cpm_ctx *c)
     HIP_TRY(hipGetLastError());
     c->ds_ok = true;
     // the travel rows of this datamatrix are those just written: bitmap words + the longest row's cells must fit the travel kernel's LDS
-    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(c->ds_max) * sizeof(double2);
+    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(c->ds_max) * sizeof(cpm::TravelCell);
     if (lds <= 32 * 1024) {
         c->tts_lds = lds;
         c->tts_valid = true;
@@ -574,12 +574,12 @@ int32_t build_sparse_travel_rows(cpm_ctx *c)
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof h_max, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&h_total, d_total, sizeof h_total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(h_max) * sizeof(double2);
+    const size_t lds = ((static_cast<size_t>(W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(h_max) * sizeof(cpm::TravelCell);
     if (lds > 32 * 1024 || h_total >= (1ull << 32)) return CPM_OK;  // dense rows: the travel kernel gathers from the dense table
     if (h_total > c->tts_cells_cap) {
         dfree(c->d_tts_cells);
         c->tts_cells_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(double2) * std::max<size_t>(h_total, 1)));
+        HIP_TRY(hipMalloc(&c->d_tts_cells, sizeof(cpm::TravelCell) * std::max<size_t>(h_total, 1)));
         c->tts_cells_cap = h_total;
     }
     hipLaunchKernelGGL(cpm::k_tts_cells, tgrid, dim3(64), 0, c->stream, c->d_dm, c->d_tts_words, c->d_tts_off, c->d_tts_cells,

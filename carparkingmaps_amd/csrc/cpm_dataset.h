@@ -8,7 +8,7 @@
 // a weight -- goes into the compact row of its (hour, origin): {x = (m - min) / (max - min), mean, std, destination}.  Everything else
 // works on those rows, 9 % of the data:
 //   * k_ds_sort    : a row's cells by destination (they arrive in the order of the atomic tickets), and with them the travel rows
-//                    the travel kernel stages (bitmap + cells in front, then (mean, 1 / (2 sigma^2)): cpm_grouped.h);
+//                    the travel kernel stages (bitmap + cells in front, then (mean, sigma, window mass): cpm_grouped.h);
 //   * k_ds_pdrive  : mean_sum[i,t] = mean over non-zero j of mean / dist (src/createpdrive.jl:14-20): the reference's loop skips
 //                    the zero cells itself, so the sequential sum over the row's cells in destination order IS its sum;
 //   * k_ds_pdest   : weights x^e_dest, the row sum, the division, the running sum (src/createpdestin.jl:19-46, src/resampling.jl:39)
@@ -186,9 +186,9 @@ __device__ __forceinline__ void ds_seq_walk(uint32_t n, const double *v, F &&ste
 // A row's cells in destination order, in place -- the rank of a cell is the number of cells with a smaller destination, which the
 // row's bitmap knows (destinations are distinct): cells in front of its word + the bits below its own -- and the row as the travel
 // kernel stages it: words[w] = (bitmap of destinations 32 w .. 32 w + 31 that hold a cell, cells in front of word w), cells (mean,
-// 1 / (2 sigma^2)) with sigma = std, or a tenth of the mean where the data hold none (src/resampling.jl:65-67).
+// sigma, mass of the window) with sigma = std, or a tenth of the mean where the data hold none (src/resampling.jl:65-67).
 __global__ __launch_bounds__(kDsThreads * kDsRows) void k_ds_sort(DsCell *__restrict__ cells, const uint32_t *__restrict__ cnt, uint32_t cap, int64_t rows, int Z,
-                                                                  uint2 *__restrict__ words, int W, double2 *__restrict__ tcells)
+                                                                  uint2 *__restrict__ words, int W, TravelCell *__restrict__ tcells)
 {
     extern __shared__ uint32_t ds_bits[];  // per wave: [W] bitmap, then [W] cells in front
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -229,7 +229,11 @@ __global__ __launch_bounds__(kDsThreads * kDsRows) void k_ds_sort(DsCell *__rest
             const uint32_t rank = bits[W + (c.j >> 5)] + static_cast<uint32_t>(__popc(bits[c.j >> 5] & ((1u << (c.j & 31u)) - 1u)));
             g[rank] = c;
             const double s1 = (c.sd == 0) ? 0.1 * c.m : c.sd;
-            tcells[row * cap + rank] = make_double2(c.m, truncnormal_inv2s2(s1));
+            TravelCell tc;
+            tc.mu = c.m;
+            tc.sigma = s1;
+            tc.mass = truncnormal_mass(c.m, s1);
+            tcells[row * cap + rank] = tc;
         }
     }
     if (live)

@@ -1798,8 +1798,12 @@ inline int travel_block(int64_t mean_bucket, bool heavy_seen)
     if (heavy_seen || mean_bucket > 4096) return 256;
     return mean_bucket > 2048 ? 128 : 64;
 }
-// LDS of a travel block on sparse rows: the largest row, then eight (cell, car) list entries per thread
-inline size_t travel_lds_bytes(size_t row_bytes, int block) { return row_bytes + static_cast<size_t>(8) * 8 * block; }
+// LDS of a travel block on sparse rows: the largest row
+inline size_t travel_lds_bytes(size_t row_bytes, int block)
+{
+    (void)block;
+    return row_bytes;
+}
 
 // The travel kernel gathers (mean, std) of its drivers' (origin, destination, hour) cells.  In the reference's datamatrix layout
 // [2][T][dest][origin] the two values lie Z*Z*T*8 B apart and consecutive destinations of one origin Z*8 B apart: two cache lines per
@@ -1919,7 +1923,7 @@ __global__ __launch_bounds__(1024) void k_tts_offsets(const uint32_t *__restrict
     if (tid == 1023) off[rows] = static_cast<uint32_t>(acc);
 }
 __global__ __launch_bounds__(64) void k_tts_cells(const double *__restrict__ dm, const uint2 *__restrict__ words, const uint32_t *__restrict__ off,
-                                                  double2 *__restrict__ cells, int Z, int T, int W)
+                                                  TravelCell *__restrict__ cells, int Z, int T, int W)
 {
     const int o = blockIdx.x * 64 + threadIdx.x, t = blockIdx.y;
     const int wper = (W + kTtsSplit - 1) / kTtsSplit, w0 = blockIdx.z * wper, w1 = min(W, w0 + wper);
@@ -1928,7 +1932,7 @@ __global__ __launch_bounds__(64) void k_tts_cells(const double *__restrict__ dm,
     const double *src = dm + static_cast<size_t>(o) + static_cast<size_t>(Z) * Z * t;
     const size_t row = static_cast<size_t>(t) * Z + o;
     const uint2 *wr = words + row * W;
-    double2 *dst = cells + off[row];
+    TravelCell *dst = cells + off[row];
     for (int w = w0; w < w1; ++w) {
         const uint2 word = wr[w];
         uint32_t at = word.y;
@@ -1944,10 +1948,14 @@ __global__ __launch_bounds__(64) void k_tts_cells(const double *__restrict__ dm,
 #pragma unroll
             for (int u = 0; u < kTtsBatch; ++u)
                 if (word.x & (1u << (h + u))) {
-                    // a cell as the travel kernel uses it: (mean, 1 / (2 sigma^2)) with sigma = std, or a tenth of the mean where the data
-                    // hold no std (src/resampling.jl:65-67) -- the division of the sampler (truncnormal_pm10), done once per cell instead of per driver
+                    // a cell as the travel kernel uses it: (mean, sigma, mass of the window) with sigma = std, or a tenth of the mean where the
+                    // data hold no std (src/resampling.jl:65-67) -- the window's mass (truncnormal_mass: an erf) once per cell instead of per driver
                     const double s1 = (sdv[u] == 0) ? 0.1 * m[u] : sdv[u];
-                    dst[at++] = make_double2(m[u], truncnormal_inv2s2(s1));
+                    TravelCell tc;
+                    tc.mu = m[u];
+                    tc.sigma = s1;
+                    tc.mass = truncnormal_mass(m[u], s1);
+                    dst[at++] = tc;
                 }
         }
     }
@@ -1958,7 +1966,7 @@ struct TravelArgs {
     const uint2 *tts_words;       // sparse rows (k_tts_*): [T*Z][W] (bitmap, cells in front), or null: gather from tt
     const uint32_t *tts_off;      // [T*Z + 1] first cell of every row -- or, fixed-stride rows (tts_stride != 0, cpm_dataset.h): [T*Z] cells per row
     uint32_t tts_stride;          // ... the row's cells start at row * tts_stride
-    const double2 *tts_cells;     // the non-zero cells, row by row: (mean, 1 / (2 sigma^2))
+    const TravelCell *tts_cells;  // the non-zero cells, row by row: (mean, sigma, mass of the window)
     int W;                        // bitmap words per row
     uint32_t list_off;            // sparse rows: byte offset of the threads' driver lists in the block's LDS (behind the largest row)
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
@@ -1987,7 +1995,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     const int z = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     uint2 *row_words = reinterpret_cast<uint2 *>(travel_lds);
-    double2 *row_cells = reinterpret_cast<double2 *>(travel_lds + ((static_cast<size_t>(tr.W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)));
+    TravelCell *row_cells = reinterpret_cast<TravelCell *>(travel_lds + ((static_cast<size_t>(tr.W) * sizeof(uint2) + 15) & ~static_cast<size_t>(15)));
     if constexpr (SPARSE) {  // (requested first: lands under the prefix scan of the run lengths)
         const size_t row = static_cast<size_t>(hour) * Z + z;
         const size_t c0 = tr.tts_stride ? row * tr.tts_stride : tr.tts_off[row];
@@ -2013,14 +2021,12 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
     const uint32_t idmask = (idbits >= 32) ? 0xFFFFFFFFu : ((1u << idbits) - 1u);
     long long tt = 0;
     if constexpr (SPARSE) {
-        // Batches of kTravelList drivers per thread.  Front half, all lanes together: the run entries (requested together), the
-        // destinations, the cell of each in the staged row; drivers inside the zone are done (300 s), the others go on the thread's
-        // list in LDS: (cell, car).  Back half: every lane works its list off, ONE attempt of the rejection sampler per trip whatever
-        // driver it is at -- a wave leaves when its slowest lane has made the attempts of all ITS drivers (~1.2 per driver), not the
-        // largest number of attempts among 64 drivers, driver after driver (3.2 of which 1.2 were needed: the kernel was 2/3 idle lanes).
+        // Batches of kTravelList drivers per thread: the run entries (requested together), the destinations, the cell of each in the
+        // staged row, ONE draw each (truncnormal_draw: the window's mass comes with the cell); drivers inside the zone take 300 s.
+        // (The rejection sampler of rounds 1-3 kept per-lane lists of (cell, car) in LDS so that a lane made one attempt per trip
+        //  whatever driver it was at; with one draw per driver there is nothing to balance.)
         constexpr int kTravelList = 8;
         constexpr uint32_t kNoCell = 0xFFFFFFFFu;
-        uint2 *list = reinterpret_cast<uint2 *>(travel_lds + tr.list_off);
         const uint32_t nthr = blockDim.x;
         for (uint32_t base = 0; base < total; base += kTravelList * nthr) {
             uint32_t w[kTravelList], gq[kTravelList];
@@ -2037,8 +2043,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
                 gq[u] = g;
                 w[u] = live[u] ? D[(static_cast<size_t>(z) * kGroups + g) * scap + (i - prefix[g])] : 0u;
             }
-            uint32_t n = 0;
-#pragma unroll
+#pragma unroll 2
             for (int u = 0; u < kTravelList; ++u) {
                 if (!live[u]) continue;
                 const uint32_t dest = (gq[u] << tr.gshift) + (w[u] >> idbits);
@@ -2048,37 +2053,17 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
                     const uint2 rw = row_words[dest >> 5];
                     const uint32_t bit = 1u << (dest & 31u);
                     const uint32_t cell = (rw.x & bit) ? rw.y + static_cast<uint32_t>(__popc(rw.x & (bit - 1u))) : kNoCell;
-                    list[n * nthr + tid] = make_uint2(cell, w[u] & idmask);
-                    ++n;
-                }
-            }
-            uint32_t cur = 0, k = 0;
-            double mu = 0.0, inv2s2 = 0.0;
-            uint64_t car = 0;
-            auto next_driver = [&]() {
-                const uint2 e = list[cur * nthr + tid];
-                // (no data for the pair: mean 0, std 0 -> sigma 0 -> 1 / 0, exactly what the division gives)
-                const double2 c = (e.x != kNoCell) ? row_cells[e.x] : make_double2(0.0, __builtin_inf());
-                mu = c.x;
-                inv2s2 = c.y;
-                car = tr.cars.global(e.y);
-            };
-            if (n) next_driver();
-            while (__builtin_amdgcn_ballot_w64(cur < n) != 0ull) {
-                if (cur < n) {
-                    double x;
-                    bool done = truncnormal_attempt(tr.seed, car, step, 1u + 2u * k, mu, inv2s2, x);
-                    ++k;
-                    if (!done && k == kTruncnormalAttempts) {
-                        done = true;
-                        x = mu;
+                    // (no data for the pair: mean 0, sigma 0 -> the draw is the mean, as the sampler has it)
+                    double mu = 0.0, sigma = 0.0, mass = 0.0;
+                    if (cell != kNoCell) {
+                        const TravelCell c = row_cells[cell];
+                        mu = c.mu;
+                        sigma = c.sigma;
+                        mass = c.mass;
                     }
-                    if (done) {
-                        tt += q16(x);
-                        ++cur;
-                        k = 0;
-                        if (cur < n) next_driver();
-                    }
+                    double u1, u2;
+                    car_uniforms(tr.seed, tr.cars.global(w[u] & idmask), step, 1u, u1, u2);
+                    tt += q16(truncnormal_draw(u1, mu, sigma, mass));
                 }
             }
         }
@@ -2539,7 +2524,7 @@ struct GroupedTables {
     const double2 *tt;       // [T][Z][Z] travel table (k_build_travel_table) or nullptr
     const uint2 *tts_words = nullptr;   // its sparse rows (k_tts_*), when a row fits LDS: what the travel kernel then stages per (origin, hour)
     const uint32_t *tts_off = nullptr;
-    const double2 *tts_cells = nullptr;
+    const TravelCell *tts_cells = nullptr;
     int tts_W = 0;
     size_t tts_lds = 0;      // bytes of the largest row (words + cells)
     const uint32_t *tts_cnt = nullptr;  // fixed-stride travel rows (cpm_dataset.h): cells per row; the row's cells start at row * tts_stride

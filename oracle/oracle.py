@@ -44,6 +44,9 @@ def lib():
     L.orc_uniforms.restype = None
     L.orc_exp_neg.argtypes = [dbl]
     L.orc_exp_neg.restype = dbl
+    for name, n in (("orc_log", 1), ("orc_sqrt", 1), ("orc_erf", 1), ("orc_ppnd", 1), ("orc_truncnormal_mass", 2), ("orc_truncnormal_draw", 4)):
+        getattr(L, name).argtypes = [dbl] * n
+        getattr(L, name).restype = dbl
     L.orc_createpdrive.argtypes = [_f64p, _f64p, i64, i64, dbl, dbl, dbl, _f64p]
     L.orc_createpdestin.argtypes = [_f64p, i64, i64, dbl, C.c_int, _f64p]
     L.orc_initializestates.argtypes = [i64, i64, i64, i64, _i64p, vp]

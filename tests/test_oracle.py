@@ -249,6 +249,36 @@ def test_sampled_density_matches_markov_propagation(O):
     assert zd.max() < 5.5
 
 
+def test_truncated_normal_kit_against_scipy(O):
+    """The sampler's deterministic f64 kit (no libm: +,-,*,/ and bits, so that the GPU reproduces it bit for bit) against scipy:
+    ln, sqrt, erf (Cody 1969), Phi^-1 (Wichura's PPND16) -- and the draw itself: inverse CDF of N(mu, sigma) truncated to
+    [0.9 mu, 1.1 mu], monotone in u, inside the window for every sigma."""
+    import math
+    from scipy import stats
+    L = O.lib()
+    xs = np.concatenate([np.linspace(1e-6, 0.46875, 200), np.linspace(0.46876, 4, 400), np.linspace(4.0001, 7, 100)])
+    assert max(abs(L.orc_erf(float(x)) - math.erf(x)) for x in xs) < 3e-16
+    ls = np.concatenate([10.0 ** np.linspace(-300, 0, 400)[:-1], np.linspace(0.001, 0.5, 300)])
+    assert max(abs(L.orc_log(float(x)) - math.log(x)) / abs(math.log(x)) for x in ls) < 5e-16
+    assert max(abs(L.orc_sqrt(float(x)) - math.sqrt(x)) / math.sqrt(x) for x in 10.0 ** np.linspace(-10, 3, 300)) < 5e-16
+    for r in np.concatenate([10.0 ** np.linspace(-15.5, -1.2, 300), np.linspace(0.075, 0.5, 200)[:-1]]):
+        q = 0.5 - r                               # Phi^-1(1 - r): the upper tail, conditioned on r itself (0.5 - q is exact)
+        want = stats.norm.isf(0.5 - q)
+        assert abs(L.orc_ppnd(float(q)) - want) <= 2e-15 * max(1.0, abs(want)), r
+        assert L.orc_ppnd(float(-q)) == -L.orc_ppnd(float(q))
+    for sigma in (400.0, 100.0, 60.0, 20.0, 5.0):     # windows of +-0.25 ... +-20 sigma (the tails of PPND16 from +-1.44 sigma on)
+        mu = 1000.0
+        E = L.orc_truncnormal_mass(mu, sigma)
+        a = 0.1 * mu / sigma
+        assert abs(E - (stats.norm.cdf(a) - stats.norm.cdf(-a))) < 1e-15
+        u = (np.arange(20001) + 0.5) / 20001
+        x = np.array([L.orc_truncnormal_draw(float(v), mu, sigma, E) for v in u])
+        assert x.min() >= 0.9 * mu and x.max() <= 1.1 * mu and (np.diff(x) >= 0).all()
+        tn = stats.truncnorm(-a, a, loc=mu, scale=sigma)
+        assert np.abs(x - tn.ppf(u)).max() < 1e-9
+    assert L.orc_truncnormal_draw(0.3, 5.0, 0.0, 1.0) == 5.0       # sigma 0: the mean
+
+
 def test_truncated_normal_moments(O):
     """The build's own truncated-normal sampler (the reference's is Distributions.jl, absent):
     window, symmetric mean, and the variance of N(mu, sigma) truncated at +-1 sigma."""
