@@ -60,7 +60,7 @@ __device__ __forceinline__ void wait_all(uint32_t &x, uint32_t (&id)[N])
 // first of a segment: their placing blocks sit a whole window in front) -- the bucket is complete, and the block is the hourly
 // sampler: all its cars in one pass, CPT per lane.  SPLIT: the placing blocks are still at work (the first set of a segment: they
 // wait for the last sampler workgroups of the hour before) -- first the stayers, then the wait, then the arrivals.
-template <int BLOCK, int CPT, int NQ>
+template <int BLOCK, int CPT, int NQ, bool SPARSE>
 __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int z, const int g, uint32_t *pack, SampleLds &sl)
 {
     uint32_t &s_nstay = sl.nstay, &s_bcast = sl.pad_, &s_ready = sl.ndrive;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, SPARSE ? 1 : 0), pieces = rw / 4, sh = 32 - a.G;
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     const uint32_t myx = xcc_id();
@@ -128,7 +128,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
-    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
+    const uint16_t *smap = SPARSE ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
     uint32_t hi_last = 0;
     const CarIndex cars = a.cars;
     const uint32_t top4 = (cap - 1u) << 2;
@@ -218,7 +218,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
             if (ph == 0) {  // every wave's pieces of the pack have landed (its own: waited for above)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                hi_last = hi[a.Zc - 1];
+                hi_last = hi[(SPARSE ? a.Zc : a.Z) - 1];
             }
             if constexpr (K > 0) {
                 pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok, smap);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
                 if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the table itself (wave-uniform, rare)
 #pragma unroll
                     for (int c = 0; c < K; ++c)
-                        if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
+                        if (want[c] & !ok[c]) dest[c] = search_exact_any<SPARSE>(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
                 }
                 // stayers: one ticket per wave for all its K slots
                 unsigned long long mS[K];
@@ -298,7 +298,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
             want1[0] = drive1 & (last != 0.0);
             pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1, smap);
             if (!want1[0]) dest1[0] = z;
-            else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
+            else if (!ok1[0]) dest1[0] = search_exact_any<SPARSE>(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
             const unsigned long long m1 = ballot64(valid1 & !drive1);
             uint32_t b1 = 0;
             if (lane == 0 && m1) b1 = atomicAdd(&s_nstay, static_cast<uint32_t>(__popcll(m1)));
@@ -405,7 +405,7 @@ __device__ __forceinline__ DayRole day_role(int r, int zpg, int pc, int mix)
 
 // grid = hours x per_hour blocks, per_hour = kGroups * (zones per group + chunks); hour t's arguments in hours[t] (device memory,
 // filled by k_grouped_zero from the run's bases: the same struct the hourly launches take by value)
-template <int CPT, int NQ>
+template <int CPT, int NQ, bool SPARSE = false>
 __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_day(const GroupedArgs *__restrict__ hours, int per_hour, int pc, int mix)
 {
     extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
     const DayRole role = day_role(r, zpg, pc, mix);
     if (role.j < 0) {
         if (role.g >= kGroups || role.z >= a.Z) return;
-        day_sample_body<kFusedThreads, CPT, NQ>(a, role.z, role.g, dyn, u.s);
+        day_sample_body<kFusedThreads, CPT, NQ, SPARSE>(a, role.z, role.g, dyn, u.s);
     } else {
         if (role.j >= a.pchunks) return;  // (hour 0: nothing to place; a.pchunks == pc otherwise)
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - role.j * kFusedChunk));
@@ -477,7 +477,7 @@ __device__ __forceinline__ void day_fill_hour(const GroupedDay &d, int t, Groupe
 }
 
 
-template <int CPT, int NQ>
+template <int CPT, int NQ, bool SPARSE = false>
 inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
 {
     const size_t lds = fused_lds_bytes(Zq, G, smap);
@@ -486,18 +486,22 @@ inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, 
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_day<CPT, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_day<CPT, NQ, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
     const int per_hour = kGroups * ((1 << gshift) + nchunk);
-    launch(k_grouped_day<CPT, NQ>, dim3(static_cast<unsigned>(nhours) * static_cast<unsigned>(per_hour)), dim3(kFusedThreads), lds, stream, hours, per_hour, nchunk, mix);
+    launch(k_grouped_day<CPT, NQ, SPARSE>, dim3(static_cast<unsigned>(nhours) * static_cast<unsigned>(per_hour)), dim3(kFusedThreads), lds, stream, hours, per_hour, nchunk, mix);
 }
 template <int CPT>
 inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
 {
     const int need = (pack_row_words(Zq, G, smap) / 4 + kSampleBlock - 1) / kSampleBlock;
 #define CPM_DAY_ARGS hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream
+    if (smap) {
+        grouped_launch_day_nq<CPT, 1, true>(CPM_DAY_ARGS);
+        return;
+    }
     if (need <= 1) grouped_launch_day_nq<CPT, 1>(CPM_DAY_ARGS);
     else if (need <= 2) grouped_launch_day_nq<CPT, 2>(CPM_DAY_ARGS);
     else if (need <= 3) grouped_launch_day_nq<CPT, 3>(CPM_DAY_ARGS);

@@ -414,7 +414,9 @@ struct ExactWork {
 // true when the path can run this problem (the row as a search tree, and the sort bins, must fit a CU's 160 KiB of LDS)
 inline bool exact_path_fits(int Z)
 {
-    return sizeof(double) * (size_t(1) << tree_height(Z)) + 64 <= 160 * 1024 && sizeof(uint32_t) * static_cast<size_t>(Z) + 1024 <= 160 * 1024;
+    // (64 KiB of LDS per workgroup is what a launch is granted here: a tree of 8,192 f64 + its 64-byte head asked for 65,600 B and the
+    //  launch came back "invalid argument" -- Z = 8,192 with more cars than the grouped path's packed ids hold went down with it)
+    return sizeof(double) * (size_t(1) << tree_height(Z)) + 64 <= 64 * 1024 && sizeof(uint32_t) * static_cast<size_t>(Z) + 1024 <= 64 * 1024;
 }
 
 // two cars per thread (measured at S4k: 1 -> 38.8 us, 2 -> 36.4, 3 -> 38.5, 4 -> 44.4), 512 threads

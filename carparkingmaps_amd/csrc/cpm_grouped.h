@@ -80,8 +80,8 @@ __host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4
 // smap (sparse pack, cpm_dataset.h): Zq and G of the compact row, and a u16 destination per entry behind the high words
 __host__ __device__ inline int pack_row_words(int Zq, int G, int smap = 0)  // at least 1 KiB: one whole LDS-DMA wave-instruction
 {
-    const int w = pack_guide_words(G) + Zq + (smap ? Zq / 2 : 0);  // (Zq is a multiple of 32)
-    return w < 256 ? 256 : (w + 3) / 4 * 4;
+    const int w = pack_guide_words(G) + Zq + (smap ? Zq / 2 : 0);  // (Zq is a multiple of 32, the guide of 4: whole 16-byte pieces)
+    return w < 256 ? 256 : w;
 }
 // a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
 inline bool pack_row_fits(int Z)
@@ -169,11 +169,12 @@ __global__ __launch_bounds__(kBucketBlock) void k_bucket_cars(const uint32_t *__
 
 // car-indexed state from fixed-stride buckets (end of the IVP): both ends of every region; a bucket whose ends met is flagged here
 // (the hour that filled it has no sampler launch behind it to notice)
-__global__ void k_unbucket(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt_s, const uint32_t *__restrict__ cnt_a, uint32_t cap,
+__global__ void k_unbucket(const uint32_t *__restrict__ ids, uint32_t *__restrict__ cnt_s, const uint32_t *__restrict__ cnt_a, uint32_t cap,
                            uint32_t *__restrict__ zone0, uint32_t n, unsigned long long *status)
 {
     const uint32_t z = blockIdx.x;
-    const uint32_t ns_raw = cnt_s[z] & kCntMask, na_raw = cnt_a[z];  // (the day launch leaves flags beside the stayer counts)
+    const uint32_t ns_raw = cnt_s[z] & kCntMask, na_raw = cnt_a[z];  // (the day launch leaves flags beside the stayer counts ...
+    if (threadIdx.x == 0) cnt_s[z] = ns_raw;                         //  ... and they end here: these buckets become the cached ones, which every form of the hour reads)
     const uint32_t ns = min(ns_raw, cap), na = min(na_raw, cap - ns);
     if (threadIdx.x == 0 && static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(status, 2ull);
     const uint32_t gap = cap - ns - na;
@@ -214,8 +215,6 @@ struct GroupedArgs {
     uint32_t *cntg;           // [Z][kGroups] run lengths (grouped)
     unsigned long long *parking_t, *driving_t;
     int Z, Zq, G;             // (sparse packs, cpm_dataset.h: Zq and G of the COMPACT row)
-    int Zc;                   // entries of a pack row in front of its 0xFFFFFFFF pad: Z, or the longest compact row of a sparse table
-    int smap;                 // 1: sparse pack -- the search's answer is an entry, its destination stands in the u16 map behind the high words
     int hour;                 // table hour of this launch (0-based): rare->nheavy[hour] counts its heavy buckets
     uint32_t *done_t;         // fused hour: [chunks] sampler workgroups of every chunk of origin zones that have handed their runs over
     int lag;                  // fused hour: the placing blocks of chunk j sit behind the sampler workgroups of chunk j + lag
@@ -225,6 +224,16 @@ struct GroupedArgs {
     // (ids / cnt_a above) before its sampler workgroups read them; pchunks = chunks of origin zones to place (0: nothing pending)
     const uint32_t *pD, *pcntg;
     int pchunks;
+    uint32_t cap, scap, idbits, gshift, step;
+    // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
+    //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
+    //  k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest)
+    CarIndex cars;
+    uint64_t seed;
+    // (what the round-4 forms read, BEHIND everything the hourly kernels read: the argument segment is loaded in aligned blocks, and
+    //  fields put among the hot ones cost the hourly sampler -- 106 scalar registers, at its ceiling -- six more spills)
+    int Zc;                   // entries of a pack row in front of its 0xFFFFFFFF pad: Z, or the longest compact row of a sparse table
+    int smap;                 // 1: sparse pack -- the search's answer is an entry, its destination stands in the u16 map behind the high words
     // the day in one launch (k_grouped_day, cpm_day.h): an hour's segment of the grid = the placing blocks of the hour before among
     // this hour's sampler workgroups.  sdone: [chunks] lines, sampler workgroups of THIS hour that have handed their runs over (by
     // chunk of origin zones); psdone: the same of the hour before (what the segment's placing blocks wait for); pdone: [kGroups]
@@ -234,12 +243,6 @@ struct GroupedArgs {
     const uint32_t *psdone;
     uint32_t *pdone;
     uint32_t chained;
-    uint32_t cap, scap, idbits, gshift, step;
-    // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
-    //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
-    //  k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest)
-    CarIndex cars;
-    uint64_t seed;
 };
 
 
@@ -569,11 +572,22 @@ __device__ __noinline__ uint32_t search_exact_ckpt(const GroupedRare *__restrict
 {
     const int Z = rare->Z;
     const size_t th = static_cast<size_t>(hour);
-    if (rare->sp) {
-        const size_t row = th * Z + o;
-        return search_exact_sparse(rare->sp + row * rare->scap, rare->sj + row * rare->scap, min(rare->scnt[row], rare->scap), uc, last);
-    }
+
     return search_exact_tables(rare->ckpt + th * ckpt_count(Z) * Z, rare->p + th * Z * Z, Z, o, uc, last, hint);
+}
+
+// ... of the kernels that run on sparse packs (a function of its own: what a noinline callee needs of scalar registers is added to its
+// callers', and the dense sampler has none to spare)
+__device__ __noinline__ uint32_t search_exact_sparse_rare(const GroupedRare *__restrict__ rare, int hour, int o, double uc, double last)
+{
+    const size_t row = static_cast<size_t>(hour) * rare->Z + o;
+    return search_exact_sparse(rare->sp + row * rare->scap, rare->sj + row * rare->scap, min(rare->scnt[row], rare->scap), uc, last);
+}
+template <bool SPARSE>
+__device__ __forceinline__ uint32_t search_exact_any(const GroupedRare *__restrict__ rare, int hour, int o, double uc, double last, int hint)
+{
+    if constexpr (SPARSE) return search_exact_sparse_rare(rare, hour, o, uc, last);
+    else return search_exact_ckpt(rare, hour, o, uc, last, hint);
 }
 
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -829,7 +843,9 @@ __device__ __forceinline__ void hand_off_done(uint32_t *done_chunk, int tid)
 // itself in (its stores drained) are the arrival count and the ids read -- past the L2 (sc1), as the placing blocks wrote them.
 // Slot s of the workgroup: stayer s below the stayers' count, else arrival s - ns from the TOP of the region -- a position that
 // does not depend on the arrivals' count, so count and ids are requested together.
-template <int BLOCK, int CPT, int NQ, bool GROUPED, bool FUSED, bool WAIT = false>
+// SPARSE: the row packs are sparse packs (cpm_dataset.h); a template parameter, not a.smap read at run time: the dense sampler lives
+// at its SGPR ceiling and the pointer, the flag and the branch cost it seven more scalar spills (v_readlane in its hot paths).
+template <int BLOCK, int CPT, int NQ, bool GROUPED, bool FUSED, bool WAIT = false, bool SPARSE = false>
 __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const int z, uint32_t *pack, SampleLds &sl, uint32_t *done_chunk,
                                                     const uint32_t *wait_on = nullptr, uint32_t wait_need = 0)
 {
@@ -839,14 +855,15 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t cap = a.cap;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, SPARSE ? 1 : 0), pieces = rw / 4, sh = 32 - a.G;
     // Scalar loads first, then the id loads -- written in assembly and waited for by hand: with LDS-DMA in flight hipcc
     // (ROCm 7.2) drains vmcnt to 0 at the first use of any ordinary vector load result, which would put Philox behind the whole
     // pack.  The wave issues CPT + 1 id loads, then exactly NQ LDS-DMA instructions; vmcnt retires in order, so vmcnt <= NQ
     // means the ids are in their registers.
     CPM_SSTAMP_DECL;
     CPM_SSTAMP(0);
-    uint32_t ns_raw = a.cnt_s[z] & kCntMask;  // (a day launch leaves flags beside the stayer counts)
+    uint32_t ns_raw = a.cnt_s[z];
+    if constexpr (WAIT) ns_raw &= kCntMask;  // (the hour behind a day launch: flags beside the stayer counts; grouped_run strips them from what it keeps)
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     uint32_t na_raw;
@@ -971,7 +988,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     uint32_t *runs = GROUPED ? a.D + static_cast<size_t>(z) * kGroups * a.scap : nullptr;
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
-    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
+    const uint16_t *smap = SPARSE ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
     uint32_t hi_last = 0;
     auto first_pass = [&](auto kc) {
         constexpr int K = decltype(kc)::value;
@@ -993,7 +1010,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         __syncthreads();
         CPM_SSTAMP(3);
         n = s_split ? static_cast<uint32_t>(CPT * BLOCK) : n_all;  // the cars this workgroup samples
-        hi_last = hi[a.Zc - 1];
+        hi_last = hi[(SPARSE ? a.Zc : a.Z) - 1];
         if constexpr (K > 0) {
             pack_search<K>(guide, hi, khi, want, sh, hi_last, a.Zq, dest, ok, smap);
             {
@@ -1006,7 +1023,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
                 if (__builtin_expect(any64(anyx), 0)) {  // ties and draws above the row total: the f64 row in HBM (wave-uniform, rare)
 #pragma unroll
                     for (int c = 0; c < K; ++c)
-                        if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
+                        if (want[c] & !ok[c]) dest[c] = search_exact_any<SPARSE>(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
                 }
             }
             CPM_SSTAMP(4);
@@ -1087,7 +1104,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
         want1[0] = drive1 & (last != 0.0);
         pack_search<1>(guide, hi, khi1, want1, sh, hi_last, a.Zq, dest1, ok1, smap);
         if (!want1[0]) dest1[0] = z;
-        else if (!ok1[0]) dest1[0] = search_exact_ckpt(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
+        else if (!ok1[0]) dest1[0] = search_exact_any<SPARSE>(a.rare, a.hour, z, u53(clo1[0], khi1[0]), last, khi1[0] <= hi_last ? static_cast<int>(dest1[0]) : -1);
         if (GROUPED) {
             const unsigned long long m1 = ballot64(valid1 & !drive1);
             uint32_t b1 = 0;
@@ -1153,12 +1170,12 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     hand_off_done<FUSED>(done_chunk, tid);
 }
 
-template <int BLOCK, int CPT, int NQ, bool GROUPED>
+template <int BLOCK, int CPT, int NQ, bool GROUPED, bool SPARSE = false>
 __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample(GroupedArgs a)
 {
     extern __shared__ uint32_t pack[];  // the zone's row pack: guide (u16), then Zq high words
     __shared__ SampleLds sl;
-    grouped_sample_body<BLOCK, CPT, NQ, GROUPED, false>(a, blockIdx.x, pack, sl, nullptr);
+    grouped_sample_body<BLOCK, CPT, NQ, GROUPED, false, false, SPARSE>(a, blockIdx.x, pack, sl, nullptr);
 }
 
 // The rest of the HEAVY buckets (real Uber Movement tables are peaky: a central zone can hold tens of times the mean, and one
@@ -1169,7 +1186,7 @@ __global__ __launch_bounds__(BLOCK, CPM_WPS) CPM_SGPR_ATTR void k_grouped_sample
 // or are writing them now: stayers take their slots in next hour's bucket with one global ticket per wave (cnt_next[z]), drivers are ranked per chunk in LDS and reserve their range of the zone's runs with one
 // global atomic per (chunk, destination group) on the run length, driving counts are added.  Order inside buckets and runs is
 // arbitrary anyway (a car's draws depend on its id only, counts are order-free).
-template <int BLOCK, int CPT, int NQ>
+template <int BLOCK, int CPT, int NQ, bool SPARSE = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a)
 {
     extern __shared__ uint32_t pack[];
@@ -1190,7 +1207,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     const uint32_t start0 = L * (1u + q);
     if (start0 >= n) return;
     const uint32_t b = static_cast<uint32_t>(z) * cap;
-    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, a.smap), pieces = rw / 4, sh = 32 - a.G;
+    const int gw = pack_guide_words(a.G), rw = pack_row_words(a.Zq, a.G, SPARSE ? 1 : 0), pieces = rw / 4, sh = 32 - a.G;
     const double last = a.last_t[z];
     const long long thr = a.thr_t[z];
     pack_dma<BLOCK, NQ>(pack, a.rp_t + static_cast<size_t>(z) * rw, pieces, tid);
@@ -1203,8 +1220,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
     __syncthreads();
     const uint16_t *guide = reinterpret_cast<const uint16_t *>(pack);
     const uint32_t *hi = pack + gw;
-    const uint16_t *smap = a.smap ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
-    const uint32_t hi_last = hi[a.Zc - 1];
+    const uint16_t *smap = SPARSE ? reinterpret_cast<const uint16_t *>(hi + a.Zq) : nullptr;
+    const uint32_t hi_last = hi[(SPARSE ? a.Zc : a.Z) - 1];
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t *stay_out = a.ids_next + static_cast<size_t>(z) * cap;
     uint32_t *runs = a.D + static_cast<size_t>(z) * kGroups * a.scap;
@@ -1236,7 +1253,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         if (__builtin_expect(any64(anyx), 0)) {
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                if (want[c] & !ok[c]) dest[c] = search_exact_ckpt(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
+                if (want[c] & !ok[c]) dest[c] = search_exact_any<SPARSE>(a.rare, a.hour, z, u53(clo[c], khi[c]), last, khi[c] <= hi_last ? static_cast<int>(dest[c]) : -1);
         }
         // stayers: ONE global ticket per block (the waves' counts are added up in LDS first).  All the blocks of a heavy zone -- 37
         // of them for the largest bucket of `--skew 32` -- draw on the zone's one stayer counter, its 32 run lengths and its driving
@@ -1395,7 +1412,7 @@ __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, con
             if (e0 + u * PB < ltotal) {
                 const uint32_t dl = w[u] >> idbits;
                 const uint32_t p = atomicAdd(&pl.tbins[dl], 1u);
-                if (p < cap && dl < static_cast<uint32_t>(nzl)) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
+                if (p < cap && (!SIGNAL || dl < static_cast<uint32_t>(nzl))) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = w[u] & idmask;
             }
     }
 }
@@ -1448,7 +1465,28 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     }
     if (tid == 0) s_any_long = 0;
     if (zs0 >= zs1) return;  // (uniform per block)
-    if constexpr (FUSED) {
+    // (k_grouped_hour, whose placing blocks signal nobody: the plain wait, the code the hourly launch was tuned with -- the abort-marked
+    //  form below, the guards of the write-out and the count mask together cost the headline 2.5 %, measured)
+    if constexpr (FUSED && !SIGNAL) {
+        if (wave == 0) {
+            bool ok = false;
+            for (uint32_t spins = 0; spins < spin_limit; ++spins) {
+                const uint32_t seen = from_lane0(lane == 0 ? __hip_atomic_load(done_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+                if (seen >= need) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);  // (~1 us between polls)
+            }
+            if (tid == 0) pl.go = ok ? 1u : 0u;
+        }
+        lds_barrier();  // (the polling wave's loads come after its poll matched, the other waves' after this barrier)
+        if (pl.go == 0u) {
+            if (tid == 0) atomicOr(status, 4ull);
+            return;
+        }
+    }
+    if constexpr (FUSED && SIGNAL) {
         if (wave == 0) {
             uint32_t go = 0;  // 0: gave up waiting, 1: the chunk's runs are complete, 2: a sampler workgroup of the chunk gave up (kDoneAbort)
             for (uint32_t spins = 0; spins < spin_limit; ++spins) {
@@ -1576,7 +1614,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
         }
 #pragma unroll
         for (int u = 0; u < kOutBatch; ++u)
-            if (i0 + u * kPlaceBlock < total && p[u] < cap && dl[u] < static_cast<uint32_t>(nzl))
+            if (i0 + u * kPlaceBlock < total && p[u] < cap && (!SIGNAL || dl[u] < static_cast<uint32_t>(nzl)))
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
@@ -1652,7 +1690,7 @@ constexpr int kDoneStride = 32;  // words between the hand-off counters of conse
                                  // launch queued at one memory channel: 300 us per launch instead of 30)
 constexpr int kFusedZpg = 256;   // zones per destination group the fused form is built for (Z <= 8,192)
 
-template <int CPT, int NQ>
+template <int CPT, int NQ, bool SPARSE = false>
 __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_hour(GroupedArgs a)
 {
     extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
@@ -1686,7 +1724,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         }
     }
     if (z >= 0) {
-        grouped_sample_body<kFusedThreads, CPT, NQ, true, true>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(z / kFusedChunk) * kDoneStride);
+        grouped_sample_body<kFusedThreads, CPT, NQ, true, true, false, SPARSE>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(z / kFusedChunk) * kDoneStride);
     } else {
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
 #ifdef CPM_PLACE_PRIO
@@ -1708,7 +1746,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
 // block = (g / 8) * 8 * chunks + j * 8 + g % 8 -- so the groups of the first sets are complete while later sets still run (and the
 // blocks of one group share blockIdx % 8 = one XCD).  A block only ever waits for blocks of LOWER index, which never wait themselves.
 // GROUPED = false: the last hour of a resample (sampled, never applied) behind the placing of the hour before it.
-template <int CPT, int NQ, bool GROUPED>
+template <int CPT, int NQ, bool GROUPED, bool SPARSE = false>
 __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_hour_pf(GroupedArgs a)
 {
     extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
@@ -1728,7 +1766,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         const int bs = blockIdx.x - npl, zpg = 1 << a.gshift;
         const int g = (bs & 7) + 8 * ((bs >> 3) / zpg), z = g * zpg + ((bs >> 3) % zpg);
         if (g >= kGroups || z >= a.Z) return;
-        grouped_sample_body<kFusedThreads, CPT, NQ, GROUPED, false, true>(a, z, dyn, u.s, nullptr, a.done_t + static_cast<size_t>(g) * kDoneStride,
+        grouped_sample_body<kFusedThreads, CPT, NQ, GROUPED, false, true, SPARSE>(a, z, dyn, u.s, nullptr, a.done_t + static_cast<size_t>(g) * kDoneStride,
                                                                           static_cast<uint32_t>(a.pchunks));
     }
 }
@@ -2127,7 +2165,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel_finish(unsigned long lon
 // ------------------------------------------------------------------------------------------------ launch helpers
 constexpr int kSampleBlock = 256;  // measured at S4k: 512 threads x 2 cars: 31 us, 256 x 4: 28, 128 x 8: 44
 
-template <bool GROUPED, int CPT, int NQ>
+template <bool GROUPED, int CPT, int NQ, bool SPARSE = false>
 inline void grouped_launch_nq(const GroupedArgs &a, size_t lds, hipStream_t stream)
 {
     if (lds > 48 * 1024) {  // LDS opt-in, once per device (contexts of several devices may live in one process)
@@ -2135,12 +2173,12 @@ inline void grouped_launch_nq(const GroupedArgs &a, size_t lds, hipStream_t stre
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED, SPARSE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    launch(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED>, dim3(a.Z), dim3(kSampleBlock), lds, stream, a);
+    launch(k_grouped_sample<kSampleBlock, CPT, NQ, GROUPED, SPARSE>, dim3(a.Z), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <bool GROUPED, int CPT>
@@ -2149,6 +2187,10 @@ inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
     const int words = pack_row_words(a.Zq, a.G, a.smap);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (a.smap) {  // (a sparse pack is at most kDsCap entries: one LDS-DMA instruction per wave; sparse_shape_ok)
+        grouped_launch_nq<GROUPED, CPT, 1, true>(a, lds, stream);
+        return;
+    }
     if (need <= 1) grouped_launch_nq<GROUPED, CPT, 1>(a, lds, stream);
     else if (need <= 2) grouped_launch_nq<GROUPED, CPT, 2>(a, lds, stream);
     else if (need <= 3) grouped_launch_nq<GROUPED, CPT, 3>(a, lds, stream);
@@ -2168,7 +2210,7 @@ inline size_t fused_lds_bytes(int Zq, int G, int smap = 0)
 {
     return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G, smap)), static_cast<size_t>(4 + sizeof(PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg>::zone_t)) * kFusedKruns * kFusedKdeep * kFusedThreads);
 }
-template <int CPT, int NQ>
+template <int CPT, int NQ, bool SPARSE = false>
 inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
 {
     const size_t lds = fused_lds_bytes(a.Zq, a.G, a.smap);
@@ -2177,14 +2219,14 @@ inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour<CPT, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour<CPT, NQ, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
     const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
     const unsigned blocks = a.lag >= nchunk ? static_cast<unsigned>(((a.Z + 7) & ~7) + nchunk * kGroups)
                                             : static_cast<unsigned>((nchunk + a.lag) * (kFusedChunk + kGroups));
-    launch(k_grouped_hour<CPT, NQ>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
+    launch(k_grouped_hour<CPT, NQ, SPARSE>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
 }
 // true when an instantiation exists for this problem (the common pack sizes; others take two launches per hour)
 inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
@@ -2206,6 +2248,10 @@ template <int CPT>
 inline void grouped_launch_hour_c(const GroupedArgs &a, hipStream_t stream)
 {
     const int need = (pack_row_words(a.Zq, a.G, a.smap) / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (a.smap) {
+        grouped_launch_hour_nq<CPT, 1, true>(a, stream);
+        return;
+    }
     if (need <= 1) grouped_launch_hour_nq<CPT, 1>(a, stream);
     else if (need <= 2) grouped_launch_hour_nq<CPT, 2>(a, stream);
     else if (need <= 3) grouped_launch_hour_nq<CPT, 3>(a, stream);
@@ -2224,7 +2270,7 @@ inline void grouped_launch_hour(const GroupedArgs &a, int64_t mean, hipStream_t 
     }
 }
 
-template <int CPT, int NQ, bool GROUPED>
+template <int CPT, int NQ, bool GROUPED, bool SPARSE = false>
 inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
 {
     const size_t lds = fused_lds_bytes(a.Zq, a.G, a.smap);
@@ -2233,16 +2279,20 @@ inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour_pf<CPT, NQ, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour_pf<CPT, NQ, GROUPED, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    launch(k_grouped_hour_pf<CPT, NQ, GROUPED>, dim3(static_cast<unsigned>(a.pchunks * kGroups + (kGroups << a.gshift))), dim3(kFusedThreads), lds, stream, a);
+    launch(k_grouped_hour_pf<CPT, NQ, GROUPED, SPARSE>, dim3(static_cast<unsigned>(a.pchunks * kGroups + (kGroups << a.gshift))), dim3(kFusedThreads), lds, stream, a);
 }
 template <int CPT, bool GROUPED>
 inline void grouped_launch_hour_pf_c(const GroupedArgs &a, hipStream_t stream)
 {
     const int need = (pack_row_words(a.Zq, a.G, a.smap) / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (a.smap) {
+        grouped_launch_hour_pf_nq<CPT, 1, GROUPED, true>(a, stream);
+        return;
+    }
     if (need <= 1) grouped_launch_hour_pf_nq<CPT, 1, GROUPED>(a, stream);
     else if (need <= 2) grouped_launch_hour_pf_nq<CPT, 2, GROUPED>(a, stream);
     else if (need <= 3) grouped_launch_hour_pf_nq<CPT, 3, GROUPED>(a, stream);
@@ -2262,7 +2312,7 @@ inline void grouped_launch_hour_pf(const GroupedArgs &a, int64_t mean, hipStream
     }
 }
 
-template <int CPT, int NQ>
+template <int CPT, int NQ, bool SPARSE = false>
 inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, size_t lds, hipStream_t stream)
 {
     if (lds > 48 * 1024) {
@@ -2270,12 +2320,12 @@ inline void grouped_launch_heavy_nq(const GroupedArgs &a, int parts, int hgrid, 
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample_heavy<kSampleBlock, CPT, NQ>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_sample_heavy<kSampleBlock, CPT, NQ, SPARSE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ>), dim3(hgrid), dim3(kSampleBlock), lds, stream, a);
+    hipLaunchKernelGGL((k_grouped_sample_heavy<kSampleBlock, CPT, NQ, SPARSE>), dim3(hgrid), dim3(kSampleBlock), lds, stream, a);
 }
 
 template <int CPT>
@@ -2284,6 +2334,10 @@ inline void grouped_launch_heavy_c(const GroupedArgs &a, int parts, int hgrid, h
     const int words = pack_row_words(a.Zq, a.G, a.smap);
     const size_t lds = sizeof(uint32_t) * static_cast<size_t>(words);
     const int need = (words / 4 + kSampleBlock - 1) / kSampleBlock;
+    if (a.smap) {
+        grouped_launch_heavy_nq<CPT, 2, true>(a, parts, hgrid, lds, stream);
+        return;
+    }
     if (need <= 2) grouped_launch_heavy_nq<CPT, 2>(a, parts, hgrid, lds, stream);
     else if (need <= 5) grouped_launch_heavy_nq<CPT, 5>(a, parts, hgrid, lds, stream);
     else if (need <= 12) grouped_launch_heavy_nq<CPT, 12>(a, parts, hgrid, lds, stream);
@@ -2713,8 +2767,11 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.hour = t;
         a.ids_next = ids_next;
         a.cnt_next = cnt_next;
-        a.D = w.Dq + w.run_words() * (history ? t : (t % w.run_hours));
-        a.cntg = w.cntg + w.len_words() * (history ? t : (t % w.run_hours));
+        // (the hourly launches alternate between TWO copies: rotating over the three the day launch needs touched half as much memory
+        //  again per resample and cost the headline 3 %)
+        const int copy = history ? t : (day_n >= 2 ? t % w.run_hours : (t & 1));  // (behind a day launch its rotation carries on: the pending runs lie in copy (t - 1) % 3)
+        a.D = w.Dq + w.run_words() * copy;
+        a.cntg = w.cntg + w.len_words() * copy;
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.step = step;
@@ -2800,7 +2857,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     }
     flush_pending();  // (an IVP ends on a placing: its final buckets are read below)
     if (ivp) {
-        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, cnt, cnt + Z, w.cap, d_zone0_out, static_cast<uint32_t>(n), status);
+        hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, const_cast<uint32_t *>(cnt), cnt + Z, w.cap, d_zone0_out, static_cast<uint32_t>(n), status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");
         w.ivp_ids = ids;
         w.ivp_cnt = cnt;
