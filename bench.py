@@ -141,9 +141,10 @@ def pmc_traffic(Z, cars_per_gpu, skew):
             continue
         name, _, grid = k.partition(" @grid=")
         grid = int(grid) if grid else None
-        if "k_grouped_hour<4, 5>" in name:                   # the fused hour at Z = 4,096 (NQ = 5): sampler workgroups + placing blocks
+        targs = [x.strip() for x in name.split("<", 1)[1].split(">", 1)[0].split(",")] if "<" in name else []
+        if "k_grouped_hour<" in name and targs[:2] == ["4", "5"] and targs[2:] in ([], ["false"]):   # the fused hour at Z = 4,096 (CPT 4, NQ 5, dense packs)
             key = "hour"
-        elif "k_grouped_sample<" in name and ", true>(" in name:   # (the grouped form; the plain form only runs hour 24)
+        elif "k_grouped_sample<" in name and len(targs) >= 4 and targs[3] == "true" and targs[4:] in ([], ["false"]):   # (the grouped form on dense packs; the plain form only runs hour 24)
             key = "sampler"
         elif "k_grouped_place" in name:
             key = "place"
@@ -453,6 +454,7 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="skip the two-resamples-in-flight figure (profiling runs: its launches overlap, "
                                                            "which would blur the per-kernel statistics)")
     ap.add_argument("--no-side", action="store_true", help="skip the secondary records (table_build, per_dataset, skewed, strong, configs3)")
+    ap.add_argument("--skip-side", default="", help="comma-separated side records to leave out (profiling passes: melbourne, per_rank_emulated, per_dataset, skewed, table_build)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -563,15 +565,21 @@ def main():
     side = {}
     if not args.no_side and not args.skew and not args.melbourne and Z == 4096 and args.cars_per_zone == 1000:
         if world == 1:
+            skip = set(x for x in args.skip_side.split(",") if x)
             traffic0, _ = pmc_traffic(Z, count, args.skew)
-            side["table_build"] = table_build_record(s, Z, traffic0)
-            side["per_dataset"] = per_dataset_record(env)
-            side["melbourne"] = melbourne_record(env)
-            side["per_rank_emulated"] = per_rank_emulated_record(env)
-            rec, j2 = side_record(env, Z, cpz, 20, "the headline workload on skewed destination tables (popularity 1 / (32 + rank): the shape of real "
-                                  "Uber Movement rows, README.md output_24_0.svg); bucket regions grown by the context as needed", skew=32)
-            j2.close()
-            side["skewed"] = rec
+            if "table_build" not in skip:
+                side["table_build"] = table_build_record(s, Z, traffic0)
+            if "per_dataset" not in skip:
+                side["per_dataset"] = per_dataset_record(env)
+            if "melbourne" not in skip:
+                side["melbourne"] = melbourne_record(env)
+            if "per_rank_emulated" not in skip:
+                side["per_rank_emulated"] = per_rank_emulated_record(env)
+            if "skewed" not in skip:
+                rec, j2 = side_record(env, Z, cpz, 20, "the headline workload on skewed destination tables (popularity 1 / (32 + rank): the shape of real "
+                                      "Uber Movement rows, README.md output_24_0.svg); bucket regions grown by the context as needed", skew=32)
+                j2.close()
+                side["skewed"] = rec
         else:
             # what BASELINE.json asks of an N-GPU run beside the weak line: the metric's own fleet dealt over the ranks ...
             rec, j2 = side_record(env, Z, 1000, 40, f"strong scaling: the metric's own configuration (Z = 4,096 x 1,000 cars/zone, C = 4,096,000) "

@@ -933,7 +933,7 @@ int32_t cpm_get_info(cpm_ctx *c, int32_t what, int64_t *value_out)
     case CPM_INFO_FUSED:
         *value_out = (pick_kernel(c) == CPM_KERNEL_ZONE_GROUPED && c->zg.fused_ok && c->zg.parts <= 1 &&
                       cpm::fused_shape_ok(static_cast<int>(c->Z), c->Zq, c->pk_G, c->sparse_tables) &&
-                      (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, c->pk_G, c->cu_count, c->sparse_tables)))
+                      (!c->zg.fused_auto || cpm::fused_pays(static_cast<int>(c->Z), c->Zq, c->pk_G, c->cu_count, c->sparse_tables, (c->n + c->Z - 1) / std::max<int64_t>(c->Z, 1))))
                          ? (c->zg.fused_day ? 6 : (c->zg.fused_pf ? 3 : 1))
                          : 0;
         return CPM_OK;

@@ -81,7 +81,11 @@ __host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4
 __host__ __device__ inline int pack_row_words(int Zq, int G, int smap = 0)  // at least 1 KiB: one whole LDS-DMA wave-instruction
 {
     const int w = pack_guide_words(G) + Zq + (smap ? Zq / 2 : 0);  // (Zq is a multiple of 32, the guide of 4: whole 16-byte pieces)
+#ifdef CPM_PACK_ALIGN  // (experiment: rows on whole 128-byte lines)
+    return w < 256 ? 256 : (w + 31) / 32 * 32;
+#else
     return w < 256 ? 256 : w;
+#endif
 }
 // a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
 inline bool pack_row_fits(int Z)
@@ -2239,8 +2243,11 @@ inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
 // 0.760, 2,000: 2.21 / 2.21), 5,120: 1.283 / 1.362, 6,144: 1.680 / 1.615, 8,192 x 500: 2.19 / 2.07.  It pays from two rounds of sampler
 // workgroups on (12 per CU) while the blocks' LDS -- every block of the fused launch carries the row pack's -- leaves five per
 // CU: below, the one launch has no second round to tuck its placing blocks behind; above, the placing blocks sit four to a CU.
-inline bool fused_pays(int Z, int Zq, int G, int cu_count, int smap = 0)
+// Sparse packs (cpm_dataset.h: a few KB per row): measured at Z = 2,357 on Melbourne-shaped tables, one launch / two launches per hour,
+// ms per resample: 1,000 cars per zone 0.721 / 0.742, 100 cars per zone 0.331 / 0.322 -- one launch from ~500 cars per zone on.
+inline bool fused_pays(int Z, int Zq, int G, int cu_count, int smap = 0, int64_t mean = 0)
 {
+    if (smap) return mean >= 512 && Z >= 6 * std::max(cu_count, 1);
     const size_t lds = fused_lds_bytes(Zq, G, smap) + 4608;  // (+ the static part: SampleLds / PlaceLds)
     return Z >= 12 * std::max(cu_count, 1) && 5 * lds <= 160 * 1024;
 }
@@ -2423,13 +2430,19 @@ namespace cpm {
 
 // ------------------------------------------------------------------------------------------------ workspace and driver
 // run capacity: a quarter of a bucket region (= the mean bucket size at cap_mult 4), >= 64, whole 128-B lines
-inline uint32_t grouped_scap(uint32_t cap) { return (std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u; }
+// ... an ODD number of 128-B lines: with 1,024 entries per run (S4k) the 32 runs of a zone lay 4 KiB apart and the same group's runs of
+// consecutive zones 128 KiB apart -- powers of two, a sampler's flush and a placing block's 64 run heads all on the same few memory
+// channels: 0.887 -> 0.858 ms per resample with one line of padding per run (same box, four interleaved runs each, +-0.001; on another
+// box 0.874 -> 0.851: the unpadded form also flipped between 0.86 and 0.89 from process to process, the padded one does not)
+inline uint32_t odd_lines(uint32_t words) { return ((words / 32u) & 1u) == 0u ? words + 32u : words; }
+inline uint32_t grouped_scap(uint32_t cap) { return odd_lines((std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u); }
 inline uint32_t grouped_gshift(int Z) { return grouped_gshift_of(Z); }
 // packed driver = id | (dest mod 2^gshift) << idbits
 inline uint32_t grouped_idbits(int Z) { return 32u - std::max(1u, grouped_gshift(Z)); }
 inline uint32_t grouped_cap(int64_t n, int Z, int cap_mult)
 {
     const int64_t mean = (n + Z - 1) / Z;
+    // (an odd number of lines per bucket region as well -- 2,048-entry regions, Z = 8,192 x 500, lie 8 KiB apart -- was measured: no difference)
     return static_cast<uint32_t>((std::max<int64_t>(cap_mult * mean, 1024) + 63) / 64 * 64);
 }
 
@@ -2645,7 +2658,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     const int64_t mean = (n + Z - 1) / Z;
     const int hours = ivp ? T - 1 : T;
     // one launch for the hour (sampler workgroups + the placing blocks of their drivers) while no heavy bucket has been seen
-    const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G, tb.smap) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count, tb.smap));
+    const bool shape = w.fused_ok && w.parts <= 1 && fused_shape_ok(Z, tb.Zq, G, tb.smap) && (!w.fused_auto || fused_pays(Z, tb.Zq, G, cu_count, tb.smap, mean));
     // ... and one launch for ALL hours that are applied (k_grouped_day): the IVP's T - 1, a resample's first T - 1 (hour T is sampled,
     // never applied: the plain form behind the placing of hour T - 1, k_grouped_hour_pf); hourly travel launches need hourly boundaries
     const int day_n = (shape && w.fused_day && w.cap < (1u << kCntXccShift) && (!travel || history)) ? (ivp ? hours : hours - 1) : 0;

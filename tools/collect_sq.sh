@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-pair ${BENCH_ARGS}"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-pair --no-side ${BENCH_ARGS}"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
@@ -22,7 +22,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        if 'k_grouped_sample' in k or 'k_grouped_place' in k:
+        if "k_grouped_sample" in k or "k_grouped_place" in k or "k_grouped_hour" in k:
             acc[k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
 out=[]
 for k,v in sorted(acc.items()):
