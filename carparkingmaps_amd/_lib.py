@@ -26,7 +26,7 @@ SYMBOLS = [
 CPM_FLAG_TRAVEL = 1
 CPM_KERNEL_AUTO, CPM_KERNEL_CAR, CPM_KERNEL_ZONE_LDS = 0, 1, 2
 CPM_KERNEL_ZONE_GROUPED = 5
-CPM_OPT_KERNEL, CPM_OPT_PROFILE, CPM_OPT_PROFILE_KERNEL, CPM_OPT_FUSED, CPM_OPT_FUSED_LAG = 1, 2, 3, 4, 5
+CPM_OPT_KERNEL, CPM_OPT_PROFILE, CPM_OPT_PROFILE_KERNEL, CPM_OPT_FUSED, CPM_OPT_FUSED_LAG, CPM_OPT_ZONE_ORDER = 1, 2, 3, 4, 5, 6
 
 _lib = None
 

@@ -902,6 +902,9 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         if (value < 1 || value > (1 << 20)) return fail(CPM_ERR_ARG, "fused lag %lld", (long long)value);
         c->zg.fused_lag = static_cast<int>(value);
         return CPM_OK;
+    case CPM_OPT_ZONE_ORDER:
+        c->zg.use_perm = value != 0;
+        return CPM_OK;
     case CPM_OPT_PROFILE_KERNEL:
         if (value < CPM_PROFILE_SAMPLER || value > CPM_PROFILE_TRAVEL) return fail(CPM_ERR_ARG, "profile kernel %lld", (long long)value);
         c->prof_what = static_cast<int>(value);

@@ -81,11 +81,7 @@ __host__ __device__ inline int pack_guide_words(int G) { return (1 << G) / 2 + 4
 __host__ __device__ inline int pack_row_words(int Zq, int G, int smap = 0)  // at least 1 KiB: one whole LDS-DMA wave-instruction
 {
     const int w = pack_guide_words(G) + Zq + (smap ? Zq / 2 : 0);  // (Zq is a multiple of 32, the guide of 4: whole 16-byte pieces)
-#ifdef CPM_PACK_ALIGN  // (experiment: rows on whole 128-byte lines)
-    return w < 256 ? 256 : (w + 31) / 32 * 32;
-#else
-    return w < 256 ? 256 : w;
-#endif
+    return w < 256 ? 256 : w;  // (rows rounded up to whole 128-byte lines: -0.3 % at S4k, within noise -- profiles/round4_notes.md)
 }
 // a row pack must fit the 150 KiB of LDS a workgroup may ask for, and a guide entry is a u16
 inline bool pack_row_fits(int Z)
@@ -247,6 +243,7 @@ struct GroupedArgs {
     const uint32_t *psdone;
     uint32_t *pdone;
     uint32_t chained;
+    const uint32_t *perm_t;   // k_grouped_hour<PERM>: [Z] the zones of this hour, largest first; null: zone order
 };
 
 
@@ -1349,6 +1346,7 @@ struct PlaceLds {
     uint32_t bins[ZPG], tbins[ZPG], delta[ZPG];
     uint32_t wsum[PB / 64], total;
     uint32_t lstart[KRUNS * (PB / 16) + 1], any_long, go;
+    uint32_t lzone[KRUNS * (PB / 16)];  // PERM (zones dealt largest-first, k_grouped_hour): the origin zone of every run of the block
     using zone_t = typename std::conditional<(ZPG <= 256), uint8_t, uint16_t>::type;  // a zone inside its group, in the sorted list
 };
 
@@ -1358,7 +1356,7 @@ struct PlaceLds {
 // 1.5 k of its 11.8 k-cycle life, tools/hour_stamps.py with finer stamps; with the pieces compiled out both vanished) -- whether the
 // jump was taken over the block or fell through in front of it: the far end of a branch costs an instruction fetch from memory.
 // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool PERM = false>
 __device__ __forceinline__ uint32_t place_surplus_entry(const PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t e)
 {
     constexpr int kRuns = (KRUNS / 2) * (PB / 8);
@@ -1367,11 +1365,11 @@ __device__ __forceinline__ uint32_t place_surplus_entry(const PlaceLds<PB, KRUNS
 #pragma unroll
     for (int step = kTop; step > 0; step >>= 1)
         if (r + step < kRuns && pl.lstart[r + step] <= e) r += step;
-    const int zc = min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + r)
+    const int zc = PERM ? static_cast<int>(pl.lzone[min(r, zs1 - zs0 - 1)]) : min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + r, or the zone dealt to that position)
     return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - pl.lstart[r])]);
 }
 // exclusive scan of the surplus lengths (one per thread), then the histogram of the surplus entries (tbins); returns their number
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED>
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool PERM = false>
 __device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits)
 {
     constexpr int kRuns = (KRUNS / 2) * (PB / 8), kSurplusBatch = 4;
@@ -1390,7 +1388,7 @@ __device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &p
         uint32_t w[kSurplusBatch];
 #pragma unroll
         for (int u = 0; u < kSurplusBatch; ++u)
-            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
+            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED, PERM>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
 #pragma unroll
         for (int u = 0; u < kSurplusBatch; ++u)
             if (e0 + u * PB < ltotal) atomicAdd(&pl.tbins[w[u] >> idbits], 1u);
@@ -1399,7 +1397,7 @@ __device__ __noinline__ uint32_t place_surplus_count(PlaceLds<PB, KRUNS, ZPG> &p
     return ltotal;
 }
 // the surplus entries straight to their buckets (tbins: the running position inside each bucket)
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL>
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL, bool PERM = false>
 __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t idbits,
                                                int zg0, int nzl, uint32_t cap, uint32_t *__restrict__ ids_next, uint32_t ltotal)
 {
@@ -1410,7 +1408,7 @@ __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, con
         uint32_t w[kSurplusBatch];
 #pragma unroll
         for (int u = 0; u < kSurplusBatch; ++u)
-            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
+            w[u] = (e0 + u * PB < ltotal) ? place_surplus_entry<PB, KRUNS, KDEEP, ZPG, FUSED, PERM>(pl, D, g, zs0, zs1, scap, e0 + u * PB) : 0u;
 #pragma unroll
         for (int u = 0; u < kSurplusBatch; ++u)
             if (e0 + u * PB < ltotal) {
@@ -1430,11 +1428,14 @@ constexpr uint32_t kFusedSpinLimit = 1u << 15;  // default number of polls: x (o
 // SIGNAL (placing first, k_grouped_hour_pf): the buckets this block fills are read by sampler workgroups of the SAME launch -- the
 // ids are stored write-through (sc1), and when the block is done every wave drains its stores, the block meets and one lane counts
 // the block in on its destination group's counter (done_out), which the group's sampler workgroups ask for before they read.
-template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL = false>
+// PERM (k_grouped_hour with its zones dealt largest-first): the runs of the block are those of the zones perm[zs0 ...] -- the
+// sampler workgroups of chunk j by POSITION in the launch.
+template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool SIGNAL = false, bool PERM = false>
 __device__ __forceinline__ void grouped_place_body(const int g, const int j, PlaceLds<PB, KRUNS, ZPG> &pl, uint32_t *sorted_ids, const uint32_t *__restrict__ D,
                                                    const uint32_t *__restrict__ cntg, int zpg, int zps, int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
                                                    uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next, unsigned long long *status,
-                                                   const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit, uint32_t *done_out = nullptr)
+                                                   const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit, uint32_t *done_out = nullptr,
+                                                   const uint32_t *__restrict__ perm = nullptr)
 {
     // A run's first 32 entries are held by EIGHT lanes, four consecutive entries each: one 16-byte load per lane and run (two 4-byte
     // loads per lane with sixteen lanes per run before: 12 load instructions per thread instead of 4, and in the fused hour, where
@@ -1517,17 +1518,25 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     }
     uint32_t c[KR], v[KR][kE], r[KR][kE];
     // (the block's runs behind one buffer descriptor: zone zs0's group-0 run is byte 0; < 2^32 bytes for every region size)
+    // (PERM: the whole run array behind the descriptor -- Z x 32 x scap x 4 B < 2^32: perm_fits)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(D) + static_cast<size_t>(zs0) * kGroups * scap, 0,
-        static_cast<int>(static_cast<uint32_t>(zs1 - zs0) * kGroups * scap * 4u), 0x00020000);
+        const_cast<uint32_t *>(D) + (PERM ? 0 : static_cast<size_t>(zs0) * kGroups * scap), 0,
+        PERM ? -1 : static_cast<int>(static_cast<uint32_t>(zs1 - zs0) * kGroups * scap * 4u), 0x00020000);
+    int zrun[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int pidx = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        zrun[k] = PERM ? static_cast<int>(perm[pidx]) : pidx;
+        if (PERM && l8 == 0) pl.lzone[sub + k * kPlaceSeg] = static_cast<uint32_t>(zrun[k]);
+    }
 #pragma unroll
     for (int k = 0; k < KR; ++k) {  // (nothing here depends on a loaded value: every request leaves before the first wait)
-        const int zc = min(zs0 + sub + k * kPlaceSeg, zs1 - 1);
+        const int zc = zrun[k];
         const size_t run = static_cast<size_t>(zc) * kGroups + g;
         c[k] = hand_load<FUSED>(&cntg[run]);
 #pragma unroll
         for (int h = 0; h < kQ; ++h) {  // (entries 32 h + 4 l8 ... of the run)
-            const cpm_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(zc - zs0) * kGroups + g) * scap + 32u * h + 4u * l8) << 2, 0,
+            const cpm_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(PERM ? zc : zc - zs0) * kGroups + g) * scap + 32u * h + 4u * l8) << 2, 0,
                                                                       FUSED ? 16 : 0);  // (aux 16: sc1)  scap >= 64; beyond c[k]: stale, masked
             v[k][4 * h + 0] = q.x;
             v[k][4 * h + 1] = q.y;
@@ -1564,7 +1573,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
     CPM_PSTAMP(3);
     const bool any_long = __builtin_amdgcn_readfirstlane(static_cast<int>(s_any_long)) != 0;  // (block-uniform, in a scalar register)
     uint32_t ltotal = 0;
-    if (any_long) ltotal = place_surplus_count<PB, KRUNS, KDEEP, ZPG, FUSED>(pl, D, g, zs0, zs1, scap, idbits);
+    if (any_long) ltotal = place_surplus_count<PB, KRUNS, KDEEP, ZPG, FUSED, PERM>(pl, D, g, zs0, zs1, scap, idbits);
     // The ticket (this block's range inside each bucket of the group) is requested now and needed only when the sorted list is
     // written out: its round trip runs under the block scan of the histogram (the zones' offsets in the sorted list) and the sort.
     const bool zone = tid < nzl;
@@ -1622,7 +1631,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
     }
     // ... and the surplus of the long runs straight to their buckets
-    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL>(pl, D, g, zs0, zs1, scap, idbits, zg0, nzl, cap, ids_next, ltotal);
+    if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL, PERM>(pl, D, g, zs0, zs1, scap, idbits, zg0, nzl, cap, ids_next, ltotal);
     CPM_PSTAMP(7);
 #if defined(CPM_DIAGNOSTIC) && !defined(CPM_STAMP_SAMPLER) && !defined(CPM_STAMP_BOTH)
     st_[7] = (st_[7] & ~1ull) | (any_long ? 1ull : 0ull);  // (the tick's lowest bit: did this block take the long-run path)
@@ -1694,7 +1703,11 @@ constexpr int kDoneStride = 32;  // words between the hand-off counters of conse
                                  // launch queued at one memory channel: 300 us per launch instead of 30)
 constexpr int kFusedZpg = 256;   // zones per destination group the fused form is built for (Z <= 8,192)
 
-template <int CPT, int NQ, bool SPARSE = false>
+// PERM: sampler workgroup b takes zone a.perm_t[b] -- the zones of the hour dealt LARGEST-FIRST (k_zone_order: by their size at the same
+// hour of the initial-value problem, the same tables a day earlier) -- so that the workgroups that enter last are the short ones: buckets
+// spread from half to 2.5 x the mean, and in zone order the sampler phase ended on whatever came last.  Chunks are chunks of POSITIONS:
+// they still complete in launch order, and a placing block finds its chunk's zones through the same list.
+template <int CPT, int NQ, bool SPARSE = false, bool PERM = false>
 __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_grouped_hour(GroupedArgs a)
 {
     extern __shared__ uint32_t dyn[];  // sampler: the zone's row pack; placing block: its sorted list
@@ -1711,6 +1724,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         if (static_cast<int>(blockIdx.x) < zr) {
             z = blockIdx.x;
             if (z >= a.Z) return;
+            if constexpr (PERM) z = static_cast<int>(a.perm_t[blockIdx.x]);
         } else {
             const int b = blockIdx.x - zr;
             g = b % kGroups;
@@ -1728,15 +1742,16 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         }
     }
     if (z >= 0) {
-        grouped_sample_body<kFusedThreads, CPT, NQ, true, true, false, SPARSE>(a, z, dyn, u.s, a.done_t + static_cast<size_t>(z / kFusedChunk) * kDoneStride);
+        grouped_sample_body<kFusedThreads, CPT, NQ, true, true, false, SPARSE>(
+            a, z, dyn, u.s, a.done_t + static_cast<size_t>((PERM ? static_cast<int>(blockIdx.x) : z) / kFusedChunk) * kDoneStride);
     } else {
         const uint32_t need = static_cast<uint32_t>(min(kFusedChunk, a.Z - j * kFusedChunk));
 #ifdef CPM_PLACE_PRIO
         __builtin_amdgcn_s_setprio(CPM_PLACE_PRIO);
 #endif
-        grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true>(g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits,
-                                                                  a.cnt_next + a.Z, a.ids_next, a.rare->status, a.done_t + static_cast<size_t>(j) * kDoneStride,
-                                                                  need, a.spin_limit);
+        grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true, false, PERM>(
+            g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status,
+            a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit, nullptr, PERM ? a.perm_t : nullptr);
     }
 }
 
@@ -2214,23 +2229,29 @@ inline size_t fused_lds_bytes(int Zq, int G, int smap = 0)
 {
     return std::max(sizeof(uint32_t) * static_cast<size_t>(pack_row_words(Zq, G, smap)), static_cast<size_t>(4 + sizeof(PlaceLds<kFusedThreads, kFusedKruns, kFusedZpg>::zone_t)) * kFusedKruns * kFusedKdeep * kFusedThreads);
 }
-template <int CPT, int NQ, bool SPARSE = false>
+template <int CPT, int NQ, bool SPARSE = false, bool PERM = false>
 inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
 {
+    if constexpr (!PERM) {
+        if (a.perm_t && a.lag >= (a.Z + kFusedChunk - 1) / kFusedChunk) {  // (zones dealt largest-first: only in the samplers-then-placing order)
+            grouped_launch_hour_nq<CPT, NQ, SPARSE, true>(a, stream);
+            return;
+        }
+    }
     const size_t lds = fused_lds_bytes(a.Zq, a.G, a.smap);
     if (lds > 48 * 1024) {
         static bool attr_done[64] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour<CPT, NQ, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grouped_hour<CPT, NQ, SPARSE, PERM>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
     const int nchunk = (a.Z + kFusedChunk - 1) / kFusedChunk;
     const unsigned blocks = a.lag >= nchunk ? static_cast<unsigned>(((a.Z + 7) & ~7) + nchunk * kGroups)
                                             : static_cast<unsigned>((nchunk + a.lag) * (kFusedChunk + kGroups));
-    launch(k_grouped_hour<CPT, NQ, SPARSE>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
+    launch(k_grouped_hour<CPT, NQ, SPARSE, PERM>, dim3(blocks), dim3(kFusedThreads), lds, stream, a);
 }
 // true when an instantiation exists for this problem (the common pack sizes; others take two launches per hour)
 inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
@@ -2424,6 +2445,37 @@ __global__ __launch_bounds__(512) void k_pack_search_debug(const uint32_t *__res
     }
 }
 
+// perm[t][.] = the zones of table hour t, LARGEST bucket first: a counting sort by size class of parking[t][z] -- the bucket sizes of that
+// hour in the run that wrote `parking` (the initial-value problem: the same tables a day earlier).  What k_grouped_hour<PERM> deals its
+// sampler workgroups by; any permutation gives the same counts (the order inside a class is whatever the atomics make it).
+__global__ __launch_bounds__(1024) void k_zone_order(const unsigned long long *__restrict__ parking, uint32_t *__restrict__ perm, int Z, uint32_t shift)
+{
+    __shared__ uint32_t bins[256];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long *n = parking + static_cast<size_t>(t) * Z;
+    if (tid < 256) bins[tid] = 0;
+    __syncthreads();
+    auto key = [&](int z) {
+        const uint32_t c = static_cast<uint32_t>(min(n[z] >> shift, 255ull));
+        return 255u - c;
+    };
+    for (int z = tid; z < Z; z += 1024) atomicAdd(&bins[key(z)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const uint32_t c = bins[k];
+            bins[k] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int z = tid; z < Z; z += 1024) {
+        const uint32_t pos = atomicAdd(&bins[key(z)], 1u);
+        perm[static_cast<size_t>(t) * Z + pos] = static_cast<uint32_t>(z);
+    }
+}
+
 }  // namespace cpm
 #include "cpm_day.h"  // the hours of a run in ONE launch (k_grouped_day), built from the bodies above
 namespace cpm {
@@ -2477,6 +2529,8 @@ struct GroupedWork {
     bool fused_day = false;                                      // ... as ONE launch for all hours of a run but the last (k_grouped_day, cpm_day.h)
     int day_mix = 1;                                             // its block order: placing blocks among the sampler workgroups (1) or in front of them (0)
     GroupedArgs *day_hours = nullptr;                            // [T] the hours' arguments of a day launch (device memory, filled by k_grouped_zero)
+    uint32_t *perm = nullptr;                                    // [T][Z] the zones of every table hour, largest bucket first (k_zone_order, behind every IVP)
+    bool perm_valid = false, use_perm = false;                   // ... written at least once since the arrays were allocated; CPM_OPT_ZONE_ORDER
     int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
                                                                  // every sampler workgroup first, then every placing block
     uint32_t fused_spin = kFusedSpinLimit;
@@ -2538,6 +2592,9 @@ struct GroupedWork {
         rare = nullptr;
         if (day_hours) (void)hipFree(day_hours);
         day_hours = nullptr;
+        if (perm) (void)hipFree(perm);
+        perm = nullptr;
+        perm_valid = false;
         n = 0;
         run_hours = kDayRunCopies;
         buckets0_valid = false;
@@ -2577,6 +2634,7 @@ struct GroupedWork {
         if (e == hipSuccess) e = hipMalloc(&maxn, 2 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&rare, sizeof(GroupedRare));
         if (e == hipSuccess) e = hipMalloc(&day_hours, sizeof(GroupedArgs) * static_cast<size_t>(std::max(T, 1)));
+        if (e == hipSuccess) e = hipMalloc(&perm, sizeof(uint32_t) * static_cast<size_t>(std::max(T, 1)) * Z);
         if (e != hipSuccess) release();
         return e;
     }
@@ -2683,7 +2741,10 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.sdone = a.pdone = nullptr;
         a.psdone = nullptr;
         a.chained = 0;
+        a.perm_t = nullptr;
     };
+    // zones dealt largest-first (k_grouped_hour<PERM>): a list exists (an IVP has run on these arrays) and the run array fits 32-bit offsets
+    const bool permute = w.use_perm && w.perm_valid && static_cast<uint64_t>(Z) * kGroups * w.scap * 4u < (1ull << 32);
     if (day_n >= 2) {
         std::memset(&day.base, 0, sizeof(day.base));
         hour_base(day.base);
@@ -2788,6 +2849,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.parking_t = parking + static_cast<size_t>(t) * Z;
         a.driving_t = driving + static_cast<size_t>(t) * Z;
         a.step = step;
+        if (permute && t < T - 1) a.perm_t = w.perm + static_cast<size_t>(t) * Z;
         const bool after_day = day_n >= 2 && t == t_first;  // (the hour behind a day launch: its placing rides in front, whatever the context's own form)
         const bool pf = shape && (w.fused_pf || after_day);  // (also the last hour, in its plain form: the placing of the hour before it rides in front)
         const bool fuse = grouped && !last_hour && shape && !pf;
@@ -2869,6 +2931,13 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "travel-time sum");
     }
     flush_pending();  // (an IVP ends on a placing: its final buckets are read below)
+    if (ivp && T >= 2) {  // the zones of every table hour, largest first, for the runs that follow (a hint: any order gives the same counts)
+        uint32_t shift = 0;
+        while ((static_cast<uint64_t>(4 * std::max<int64_t>(mean, 1)) >> shift) > 255) ++shift;
+        hipLaunchKernelGGL(k_zone_order, dim3(T - 1), dim3(1024), 0, stream, parking, w.perm, Z, shift);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "zone order");
+        w.perm_valid = true;
+    }
     if (ivp) {
         hipLaunchKernelGGL(k_unbucket, dim3(Z), dim3(256), 0, stream, ids, const_cast<uint32_t *>(cnt), cnt + Z, w.cap, d_zone0_out, static_cast<uint32_t>(n), status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "unbucket");

@@ -495,6 +495,10 @@ def test_fused_hour_equals_two_launches_per_hour(cpm, O, Z, cpz, T):
             assert r["sum_tt_q16"] == ref["sum_tt_q16"], (mode, lag)
             r = s.resample(SIM_SEED)                             # (without travel times the last hour runs in its plain form)
             assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (mode, lag)
+            s.set_zone_order(False)                              # (the one-launch hour in zone order instead of largest-first: a hint, the same counts)
+            r = s.resample(SIM_SEED)
+            assert np.array_equal(r["parking"], ref["parking"]) and np.array_equal(r["driving"], ref["driving"]), (mode, lag)
+            s.set_zone_order(True)
             assert s.get_info(4) == {0: 0, 1: 1, 2: 0, 3: 3, 4: 0, 6: 6, 7: 0, 8: 6}[mode]   # after a bail-out the context keeps to two launches
             assert s.get_info(2) == 4                            # ... and did not mistake it for an overflow
 

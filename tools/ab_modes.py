@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--melbourne", action="store_true")
 ap.add_argument("--skew", type=int, default=0)
+ap.add_argument("--order", default="1", help="comma-separated CPM_OPT_ZONE_ORDER values to cross with the modes (1: zones largest-first, 0: zone order)")
 args = ap.parse_args()
 Z, T, cpz = args.zones, 24, args.cpz
 C = Z * cpz
@@ -34,12 +35,18 @@ else:
 s.init_states(C, cpz)
 s.solve_ivp(0x5EEDCA125, want=False)
 buf = torch.zeros(s.counts_words(), dtype=torch.int64, device="cuda:0")
-modes = [int(m) for m in args.modes.split(",")]
+orders = [int(o) for o in args.order.split(",")]
+modes = [(int(m), o) for m in args.modes.split(",") for o in orders]
 ref = None
 res = {m: [] for m in modes}
 for r in range(args.rounds):
     for m in modes:
-        s.set_fused(m)
+        s.set_fused(m[0])
+        s.set_zone_order(m[1])
+        if m[1] != getattr(s, "_order_built", None):      # (the list is built behind an IVP: run one with the direction asked for)
+            s.init_states(C, cpz)
+            s.solve_ivp(0x5EEDCA125, want=False)
+            s._order_built = m[1]
         for _ in range(4):
             s.resample_dev(0x5EEDCA125, buf.data_ptr())
         torch.cuda.synchronize()
