@@ -616,8 +616,16 @@ __device__ __forceinline__ void pack_dma(uint32_t *lds, const uint32_t *pack, in
 template <int N, int NQ>
 __device__ __forceinline__ void wait_ids(uint32_t (&id)[N])
 {
-    static_assert((N == 2 || N == 3 || N == 5) && NQ <= 63, "written for CPT = 1, 2, 4");
-    if constexpr (N == 5)
+    static_assert((N == 2 || N == 3 || (N >= 5 && N <= 9)) && NQ <= 63, "written for CPT = 1, 2, 4 .. 8");
+    if constexpr (N == 9)
+        asm volatile("s_waitcnt vmcnt(%9)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]), "+v"(id[6]), "+v"(id[7]), "+v"(id[8]) : "n"(NQ) : "memory");
+    else if constexpr (N == 8)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]), "+v"(id[6]), "+v"(id[7]) : "n"(NQ) : "memory");
+    else if constexpr (N == 7)
+        asm volatile("s_waitcnt vmcnt(%7)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]), "+v"(id[6]) : "n"(NQ) : "memory");
+    else if constexpr (N == 6)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]), "+v"(id[5]) : "n"(NQ) : "memory");
+    else if constexpr (N == 5)
         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]), "+v"(id[4]) : "n"(NQ) : "memory");
     else if constexpr (N == 3)
         asm volatile("s_waitcnt vmcnt(%3)" : "+v"(id[0]), "+v"(id[1]), "+v"(id[2]) : "n"(NQ) : "memory");
@@ -942,7 +950,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     CPM_SSTAMP(1);
     // A bucket beyond CPT * BLOCK cars is walked here BLOCK cars at a time -- unless it is heavy, the heavy kernel follows and has
     // room for it: then this workgroup takes the first CPT * BLOCK cars (all its slots are full either way) and lists the zone.
-    const bool heavy = n_all > a.heavy_x * CPT * BLOCK;
+    const bool heavy = n_all > a.heavy_x * (CPT > 4 ? 4 : CPT) * BLOCK;  // (the wide forms run only where no heavy launch follows: same absolute threshold as CPT = 4)
     if (tid == 0) {
         a.parking_t[z] = n_all;  // every car present at hour t, drivers included (src/saveresults.jl:12)
         if (static_cast<unsigned long long>(ns_raw) + na_raw > cap) atomicOr(a.rare->status, 2ull);  // the two ends of the bucket met: step invalid
@@ -1070,7 +1078,49 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
     {
         const uint32_t w64 = from_lane0(static_cast<uint32_t>(tid) & ~63u);  // (this wave's first slot of car 0, in a scalar register)
         const uint32_t k = n_all > w64 ? min(static_cast<uint32_t>(CPT), (n_all - w64 + BLOCK - 1) / BLOCK) : 0u;
-        if constexpr (CPT == 4) {
+        if constexpr (CPT == 8) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            case 2: first_pass(std::integral_constant<int, 2>{}); break;
+            case 3: first_pass(std::integral_constant<int, 3>{}); break;
+            case 4: first_pass(std::integral_constant<int, 4>{}); break;
+            case 5: first_pass(std::integral_constant<int, 5>{}); break;
+            case 6: first_pass(std::integral_constant<int, 6>{}); break;
+            case 7: first_pass(std::integral_constant<int, 7>{}); break;
+            default: first_pass(std::integral_constant<int, 8>{}); break;
+            }
+        } else if constexpr (CPT == 7) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            case 2: first_pass(std::integral_constant<int, 2>{}); break;
+            case 3: first_pass(std::integral_constant<int, 3>{}); break;
+            case 4: first_pass(std::integral_constant<int, 4>{}); break;
+            case 5: first_pass(std::integral_constant<int, 5>{}); break;
+            case 6: first_pass(std::integral_constant<int, 6>{}); break;
+            default: first_pass(std::integral_constant<int, 7>{}); break;
+            }
+        } else if constexpr (CPT == 6) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            case 2: first_pass(std::integral_constant<int, 2>{}); break;
+            case 3: first_pass(std::integral_constant<int, 3>{}); break;
+            case 4: first_pass(std::integral_constant<int, 4>{}); break;
+            case 5: first_pass(std::integral_constant<int, 5>{}); break;
+            default: first_pass(std::integral_constant<int, 6>{}); break;
+            }
+        } else if constexpr (CPT == 5) {
+            switch (k) {
+            case 0: first_pass(std::integral_constant<int, 0>{}); break;
+            case 1: first_pass(std::integral_constant<int, 1>{}); break;
+            case 2: first_pass(std::integral_constant<int, 2>{}); break;
+            case 3: first_pass(std::integral_constant<int, 3>{}); break;
+            case 4: first_pass(std::integral_constant<int, 4>{}); break;
+            default: first_pass(std::integral_constant<int, 5>{}); break;
+            }
+        } else if constexpr (CPT == 4) {
             switch (k) {
             case 0: first_pass(std::integral_constant<int, 0>{}); break;
             case 1: first_pass(std::integral_constant<int, 1>{}); break;
@@ -2223,6 +2273,19 @@ inline void grouped_launch_c(const GroupedArgs &a, hipStream_t stream)
 }
 
 inline int grouped_cpt(int64_t mean) { return mean <= 224 ? 1 : (mean <= 560 ? 2 : 4); }
+// ... and where no heavy bucket has been seen (the heavy launch shares the sampler's chunking: it stays with grouped_cpt): slots for
+// 1.5 x the mean bucket.  Buckets spread from half to 2.5 x the mean on flat tables, and a bucket beyond its workgroup's slots pays a
+// whole serial round (ids, Philox, search, ranks) per 256 cars more, while a wave only runs the K <= CPT cars per lane it holds
+// (first_pass): at S4k 42 % of the buckets needed such rounds with 4 cars per lane, 0.851 -> 0.815 ms per resample with 6 (same box,
+// interleaved; 5: 0.827, 7: 0.824 with 9 vector registers spilled, 8 at five waves per SIMD: 0.856 -- profiles/round4_notes.md).
+#ifndef CPM_CPT_RULE
+#define CPM_CPT_RULE 1
+#endif
+inline int grouped_cpt_wide(int64_t mean)
+{
+    if (CPM_CPT_RULE == 0) return grouped_cpt(mean);
+    return mean <= 170 ? 1 : (mean <= 340 ? 2 : (mean <= 700 ? 4 : 6));
+}
 
 // the fused hour (k_grouped_hour): (chunks + lag) x (kFusedChunk sampler workgroups + kGroups placing blocks)
 inline size_t fused_lds_bytes(int Zq, int G, int smap = 0)
@@ -2291,10 +2354,11 @@ inline void grouped_launch_hour_c(const GroupedArgs &a, hipStream_t stream)
 }
 inline void grouped_launch_hour(const GroupedArgs &a, int64_t mean, hipStream_t stream)
 {
-    switch (grouped_cpt(mean)) {
+    switch (grouped_cpt_wide(mean)) {  // (one launch per hour only while no heavy bucket has been seen)
     case 1: grouped_launch_hour_c<1>(a, stream); break;
     case 2: grouped_launch_hour_c<2>(a, stream); break;
-    default: grouped_launch_hour_c<4>(a, stream); break;
+    case 4: grouped_launch_hour_c<4>(a, stream); break;
+    default: grouped_launch_hour_c<6>(a, stream); break;
     }
 }
 
@@ -2386,12 +2450,13 @@ inline void grouped_launch_heavy(const GroupedArgs &a, int parts, int hgrid, int
 // Cars per thread by the mean bucket size (cars of this GPU / zones): 256 x 4 slots for ~1000 cars per zone, 256 x 2 and 256 x 1
 // for smaller buckets (every slot runs Philox whether a car sits in it or not); larger buckets take the overflow rounds.
 template <bool GROUPED>
-inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, hipStream_t stream)
+inline void grouped_launch_sample(const GroupedArgs &a, int64_t mean, bool heavy_follows, hipStream_t stream)
 {
-    switch (grouped_cpt(mean)) {
+    switch (heavy_follows ? grouped_cpt(mean) : grouped_cpt_wide(mean)) {
     case 1: grouped_launch_c<GROUPED, 1>(a, stream); break;
     case 2: grouped_launch_c<GROUPED, 2>(a, stream); break;
-    default: grouped_launch_c<GROUPED, 4>(a, stream); break;
+    case 4: grouped_launch_c<GROUPED, 4>(a, stream); break;
+    default: grouped_launch_c<GROUPED, 6>(a, stream); break;
     }
 }
 
@@ -2865,8 +2930,8 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         if (pf && grouped) grouped_launch_hour_pf<true>(a, mean, stream);
         else if (pf) grouped_launch_hour_pf<false>(a, mean, stream);
         else if (fuse) grouped_launch_hour(a, mean, stream);
-        else if (grouped) grouped_launch_sample<true>(a, mean, stream);
-        else grouped_launch_sample<false>(a, mean, stream);
+        else if (grouped) grouped_launch_sample<true>(a, mean, w.parts > 1, stream);
+        else grouped_launch_sample<false>(a, mean, w.parts > 1, stream);
         prof_end(CPM_PROFILE_SAMPLER);
         if (grouped && !fuse && !pf) grouped_launch_heavy(a, w.parts, w.hgrid, mean, stream);
         if (!last_hour) {
