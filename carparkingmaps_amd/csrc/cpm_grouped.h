@@ -1405,6 +1405,13 @@ struct PlaceLds {
 // dependency chain as branches over a few hundred instructions, and a placing block lost ~1.5 k cycles at each of the two (3.2 k +
 // 1.5 k of its 11.8 k-cycle life, tools/hour_stamps.py with finer stamps; with the pieces compiled out both vanished) -- whether the
 // jump was taken over the block or fell through in front of it: the far end of a branch costs an instruction fetch from memory.
+// Entries of a run its own 8 lanes take: the first 16 * KDEEP in registers at once, and in the one-launch hour (KDEEP = 2) the next 32 by a second 16-byte
+// load per lane that only the lanes of a run LONGER than 32 issue, once the run lengths have arrived (grouped_place_body: the MEDIUM
+// runs).  What lies beyond is the surplus the whole block deals out below.
+// Only in the one-launch hour (FUSED), whose blocks have the sampler's 80 registers anyway: the standalone placing kernel went from 64 to
+// 81 registers with it -- two 512-thread blocks per CU instead of four -- and lost 3 % at Z = 8,192 and 14 % on skewed tables.
+__host__ __device__ constexpr bool place_medium(int kdeep, bool fused) { return kdeep == 2 && fused; }
+__host__ __device__ constexpr uint32_t place_held(int kdeep, bool fused) { return place_medium(kdeep, fused) ? 64u : 16u * static_cast<uint32_t>(kdeep); }
 // surplus entry e of the block -> (run r, index inside the run): r = the last run with lstart[r] <= e
 template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool PERM = false>
 __device__ __forceinline__ uint32_t place_surplus_entry(const PlaceLds<PB, KRUNS, ZPG> &pl, const uint32_t *D, int g, int zs0, int zs1, uint32_t scap, uint32_t e)
@@ -1416,7 +1423,7 @@ __device__ __forceinline__ uint32_t place_surplus_entry(const PlaceLds<PB, KRUNS
     for (int step = kTop; step > 0; step >>= 1)
         if (r + step < kRuns && pl.lstart[r + step] <= e) r += step;
     const int zc = PERM ? static_cast<int>(pl.lzone[min(r, zs1 - zs0 - 1)]) : min(zs0 + r, zs1 - 1);  // (run r of the block: origin zone zs0 + r, or the zone dealt to that position)
-    return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + 16u * KDEEP + (e - pl.lstart[r])]);
+    return hand_load<FUSED>(&D[(static_cast<size_t>(zc) * kGroups + g) * scap + place_held(KDEEP, FUSED) + (e - pl.lstart[r])]);
 }
 // exclusive scan of the surplus lengths (one per thread), then the histogram of the surplus entries (tbins); returns their number
 template <int PB, int KRUNS, int KDEEP, int ZPG, bool FUSED, bool PERM = false>
@@ -1601,6 +1608,28 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
         c[k] = min(c[k], scap);  // (beyond scap only when the heavy kernel flagged an overflow: the step is repeated)
         if (zs0 + sub + k * kPlaceSeg >= zs1) c[k] = 0;
     }
+    // MEDIUM runs (33 .. 64 entries: at S4k a run holds ~16 drivers on average and 28 where p_drive is 0.9, so most blocks hold a few):
+    // entries 32 .. 63 by ONE more 16-byte load of the run's own lanes, requested now -- its round trip runs under pass A -- counted in
+    // tbins and stored straight to their buckets behind the sorted list.  They took the surplus path before (a scan of the block's runs
+    // between two barriers, a binary search over its prefix and a dependent load per entry, TWICE: ~5 k ticks of a placing block's
+    // 12.5 k in the fused hour, most blocks).
+    constexpr bool kMedium = place_medium(KDEEP, FUSED);
+    cpm_u32x4 xq[KR];
+    uint32_t nx[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        nx[k] = 0;
+        xq[k] = cpm_u32x4{0u, 0u, 0u, 0u};
+        if constexpr (kMedium) {
+            const uint32_t first = 32u + 4u * static_cast<uint32_t>(l8);
+            // this lane's entries among 32 .. 63 of the run.  (NOT `c > first ? min(c - first, 4u) : 0u`: hipcc (ROCm 7.2) hoists the
+            //  subtraction out of the conditional as `sub nuw` into min(), whose result is `noundef` -- and from there concludes c >= 32
+            //  for every lane, dropping the `entry < c` guards of pass A below: stale entries were ranked and placed.)
+            nx[k] = min(max(c[k], first) - first, 4u);
+            if (nx[k])
+                xq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((static_cast<uint32_t>(PERM ? zrun[k] : zrun[k] - zs0) * kGroups + g) * scap + first) << 2, 0, FUSED ? 16 : 0);
+        }
+    }
     // pass A: rank of every entry among the block's entries for the same destination zone (= the histogram, once all are in)
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
@@ -1610,10 +1639,19 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
             if (static_cast<uint32_t>(32 * (d / 4) + 4 * l8 + (d % 4)) < c[k]) r[k][d] = atomicAdd(&bins[v[k][d] >> idbits], 1u);
         }
     }
+    if constexpr (kMedium) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const uint32_t x4[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (static_cast<uint32_t>(d) < nx[k]) atomicAdd(&tbins[x4[d] >> idbits], 1u);
+        }
+    }
     if (l8 == 0) {
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const uint32_t surplus = c[k] > 16u * KDEEP ? c[k] - 16u * KDEEP : 0u;
+            const uint32_t surplus = c[k] > place_held(KDEEP, FUSED) ? c[k] - place_held(KDEEP, FUSED) : 0u;
             lstart[sub + k * kPlaceSeg] = surplus;
             if (surplus) s_any_long = 1u;
         }
@@ -1679,6 +1717,20 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
         for (int u = 0; u < kOutBatch; ++u)
             if (i0 + u * kPlaceBlock < total && p[u] < cap && (!SIGNAL || dl[u] < static_cast<uint32_t>(nzl)))
                 ids_next[static_cast<size_t>(zg0 + dl[u]) * cap + (cap - 1u - p[u])] = idv[u];  // arrivals fill a region from its top
+    }
+    // ... the entries 32 .. 63 of the medium runs straight to their buckets (tbins: the running position behind the sorted ones) ...
+    if constexpr (kMedium) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const uint32_t x4[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (static_cast<uint32_t>(d) < nx[k]) {
+                    const uint32_t dl = x4[d] >> idbits;
+                    const uint32_t p = atomicAdd(&tbins[dl], 1u);
+                    if (p < cap && (!SIGNAL || dl < static_cast<uint32_t>(nzl))) ids_next[static_cast<size_t>(zg0 + dl) * cap + (cap - 1u - p)] = x4[d] & idmask;
+                }
+        }
     }
     // ... and the surplus of the long runs straight to their buckets
     if (any_long) place_surplus_out<PB, KRUNS, KDEEP, ZPG, FUSED, SIGNAL, PERM>(pl, D, g, zs0, zs1, scap, idbits, zg0, nzl, cap, ids_next, ltotal);
