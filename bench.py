@@ -142,7 +142,7 @@ def pmc_traffic(Z, cars_per_gpu, skew):
         name, _, grid = k.partition(" @grid=")
         grid = int(grid) if grid else None
         targs = [x.strip() for x in name.split("<", 1)[1].split(">", 1)[0].split(",")] if "<" in name else []
-        if "k_grouped_hour<" in name and targs[:2] == ["4", "5"] and targs[2:] in ([], ["false"]):   # the fused hour at Z = 4,096 (CPT 4, NQ 5, dense packs)
+        if "k_grouped_hour<" in name and targs[:2] in (["6", "5"], ["4", "5"]) and all(x == "false" for x in targs[2:]):   # the fused hour at Z = 4,096 (six cars per lane, NQ 5, dense packs, zone order)
             key = "hour"
         elif "k_grouped_sample<" in name and len(targs) >= 4 and targs[3] == "true" and targs[4:] in ([], ["false"]):   # (the grouped form on dense packs; the plain form only runs hour 24)
             key = "sampler"
