@@ -15,7 +15,12 @@ from carparkingmaps_amd import _lib
 
 Z, T, cpz = int(os.environ.get("CPM_STAMP_Z", "4096")), 24, 1000
 s = cpm.Sampler(Z, T, 0)
-s.synth_tables(0x5EED7AB1E)
+if os.environ.get("CPM_STAMP_MELB") == "1":   # Melbourne-shaped sparse tables (one launch per hour from 512 cars per zone on)
+    s.synth_datamatrix(0x5EED7AB1E)
+    s.build_p_drive(0.1, 0.9, 0.5, want=False)
+    s.build_p_dest(2, want=False)
+else:
+    s.synth_tables(0x5EED7AB1E)
 s.init_states(Z * cpz, cpz)
 s.solve_ivp(0x5EEDCA125, want=False)
 L = _lib.load()
