@@ -903,7 +903,8 @@ int32_t cpm_set_option(cpm_ctx *c, int32_t option, int64_t value)
         c->zg.fused_lag = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_ZONE_ORDER:
-        c->zg.use_perm = value != 0;
+        if (value < 0 || value > 2) return fail(CPM_ERR_ARG, "zone order %lld (0 zone order, 1 largest-first, 2 largest-first on sparse row packs)", (long long)value);
+        c->zg.use_perm = static_cast<int>(value);
         return CPM_OK;
     case CPM_OPT_PROFILE_KERNEL:
         if (value < CPM_PROFILE_SAMPLER || value > CPM_PROFILE_TRAVEL) return fail(CPM_ERR_ARG, "profile kernel %lld", (long long)value);

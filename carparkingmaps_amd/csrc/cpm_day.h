@@ -246,7 +246,7 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
                 bS = from_lane0(bS);
                 uint32_t rank[K];
 #pragma unroll
-                for (int c = 0; c < K; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+                for (int c = 0; c < K; ++c) rank[c] = drive[c] ? atomicAdd(&gb[gdiv_group(a.gdiv, dest[c])], 1u) : 0u;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     if (valid[c] & !drive[c]) put32(stay_out, bS + static_cast<uint32_t>(__popcll(mS[c] & below)), id[c]);
@@ -255,8 +255,8 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     if (drive[c]) {
-                        const uint32_t gd = dest[c] >> a.gshift;
-                        const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                        const uint32_t gd = gdiv_group(a.gdiv, dest[c]);
+                        const uint32_t packed = id[c] | (gdiv_local(a.gdiv, dest[c], gd) << a.idbits);
                         if (rank[c] < static_cast<uint32_t>(kStage)) stage[gd * kStage + rank[c]] = packed;
                         else if (rank[c] < a.scap) hand_store<true>(&runs[gd * a.scap + rank[c]], packed);
                     }
@@ -305,9 +305,9 @@ __device__ __forceinline__ void day_sample_body(const GroupedArgs &a, const int 
             b1 = from_lane0(b1);
             if (valid1 & !drive1) stay_out[b1 + static_cast<uint32_t>(__popcll(m1 & below))] = idx;
             if (drive1) {
-                const uint32_t gd = dest1[0] >> a.gshift;
+                const uint32_t gd = gdiv_group(a.gdiv, dest1[0]);
                 const uint32_t rank = atomicAdd(&gb[gd], 1u);
-                const uint32_t packed = idx | ((dest1[0] & ((1u << a.gshift) - 1u)) << a.idbits);
+                const uint32_t packed = idx | (gdiv_local(a.gdiv, dest1[0], gd) << a.idbits);
                 if (rank < static_cast<uint32_t>(kStage)) stage[gd * kStage + rank] = packed;
                 else if (rank < a.scap) hand_store<true>(&runs[gd * a.scap + rank], packed);
             }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
     if (threadIdx.x == 0 && g_place_stamps) g_place_stamps[(static_cast<size_t>(gridDim.x) + blockIdx.x) * 8] = __builtin_amdgcn_s_memtime();
 #endif
     const GroupedArgs &a = hours[t];
-    const int zpg = 1 << a.gshift;
+    const int zpg = static_cast<int>(gdiv_zpg(a.gdiv));
     const DayRole role = day_role(r, zpg, pc, mix);
     if (role.j < 0) {
         if (role.g >= kGroups || role.z >= a.Z) return;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void day_fill_hour(const GroupedDay &d, int t, Groupe
 
 
 template <int CPT, int NQ, bool SPARSE = false>
-inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
+inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int zpg, int nchunk, int mix, hipStream_t stream)
 {
     const size_t lds = fused_lds_bytes(Zq, G, smap);
     if (lds > 48 * 1024) {
@@ -490,14 +490,14 @@ inline void grouped_launch_day_nq(const GroupedArgs *hours, int nhours, int Zq, 
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    const int per_hour = kGroups * ((1 << gshift) + nchunk);
+    const int per_hour = kGroups * (zpg + nchunk);
     launch(k_grouped_day<CPT, NQ, SPARSE>, dim3(static_cast<unsigned>(nhours) * static_cast<unsigned>(per_hour)), dim3(kFusedThreads), lds, stream, hours, per_hour, nchunk, mix);
 }
 template <int CPT>
-inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int gshift, int nchunk, int mix, hipStream_t stream)
+inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, int G, int smap, int zpg, int nchunk, int mix, hipStream_t stream)
 {
     const int need = (pack_row_words(Zq, G, smap) / 4 + kSampleBlock - 1) / kSampleBlock;
-#define CPM_DAY_ARGS hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream
+#define CPM_DAY_ARGS hours, nhours, Zq, G, smap, zpg, nchunk, mix, stream
     if (smap) {
         grouped_launch_day_nq<CPT, 1, true>(CPM_DAY_ARGS);
         return;
@@ -512,13 +512,13 @@ inline void grouped_launch_day_c(const GroupedArgs *hours, int nhours, int Zq, i
     else grouped_launch_day_nq<CPT, 12>(CPM_DAY_ARGS);
 #undef CPM_DAY_ARGS
 }
-inline void grouped_launch_day(const GroupedArgs *hours, int nhours, int Z, int Zq, int G, int smap, int gshift, int nchunk, int mix, int64_t mean, hipStream_t stream)
+inline void grouped_launch_day(const GroupedArgs *hours, int nhours, int Z, int Zq, int G, int smap, int zpg, int nchunk, int mix, int64_t mean, hipStream_t stream)
 {
     (void)Z;
     switch (grouped_cpt(mean)) {
-    case 1: grouped_launch_day_c<1>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
-    case 2: grouped_launch_day_c<2>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
-    default: grouped_launch_day_c<4>(hours, nhours, Zq, G, smap, gshift, nchunk, mix, stream); break;
+    case 1: grouped_launch_day_c<1>(hours, nhours, Zq, G, smap, zpg, nchunk, mix, stream); break;
+    case 2: grouped_launch_day_c<2>(hours, nhours, Zq, G, smap, zpg, nchunk, mix, stream); break;
+    default: grouped_launch_day_c<4>(hours, nhours, Zq, G, smap, zpg, nchunk, mix, stream); break;
     }
 }
 

@@ -19,8 +19,8 @@
 //     guide[m] = first j with hi[j] >= m << (32 - G), m = 0 .. 2^G (u16, clamped to Z - 1; G = ceil(log2 Z) - 2).
 //     A row pack = [2^G + 8 u16 guide][Zq u32 hi], Zq = Z + at least 31 entries of 0xFFFFFFFF, rounded to 32.
 //   * Stayers (about half the cars) never leave their zone: the sampler compacts them into the zone's region of next hour's id
-//     array.  Drivers go into FIXED-SIZE runs, one per (origin zone, destination group) -- 32 groups of 2^gshift consecutive
-//     zones -- at D[(z*32 + g)*scap + rank], rank from an LDS atomic, as id | (dest mod 2^gshift) << idbits.  k_grouped_place
+//     array.  Drivers go into FIXED-SIZE runs, one per (origin zone, destination group) -- 32 groups of zpg = ceil(Z / 32) consecutive
+//     zones -- at D[(z*32 + g)*scap + rank], rank from an LDS atomic, as id | (dest - g * zpg) << idbits.  k_grouped_place
 //     then moves every group's drivers into their buckets; its blocks of one group share an XCD (one L2), where the 4-byte id
 //     writes to a bucket merge before they leave.
 //   * A bucket that would outgrow cap, or a run that would outgrow scap, raises the status word (no out-of-range store is issued);
@@ -55,12 +55,58 @@ constexpr int kCntXccShift = 26;
 constexpr uint32_t kCntMask = (1u << kCntXccShift) - 1u;
 constexpr uint32_t kDoneAbort = 0x10000u, kDoneCount = 0xFFFFu;
 
-// destination groups of 2^gshift consecutive zones, at most kGroups of them
-inline uint32_t grouped_gshift_of(int Z)
+// Destination groups: kGroups groups of zpg = ceil(Z / kGroups) CONSECUTIVE zones (a placing block writes to neighbouring buckets).
+// Rounds 1-3 took zpg as a power of two (a shift and a mask per driver): Z = 2,357 then used 19 of the 32 groups, its runs were 1.7 x
+// as long -- most of them beyond what a placing block's lanes hold -- and 13 of every 32 placing blocks of the one-launch hour had
+// nothing to do (tools/hour_stamps.py, profiles/round4_notes.md).  GENERAL groups (any zpg):
+//   group(dest) = (dest * M) >> s,  M = ceil(2^s / zpg),  2^s >= Z * zpg   (exact for every dest < Z; both factors < 2^24: one
+//   full-rate v_mul_u32_u24),  packed with zpg into ONE argument word: M in bits 0..16, s in 17..21, zpg - 1 in 22..31.
+// The multiply and the subtraction per driver cost the dense headline 1.1 % (same box, interleaved), so the general form is what the
+// SPARSE sampler instantiations run (datasets: Melbourne's Z = 2,357 and its like) and dense tables keep power-of-two groups -- in the
+// same word: M = 1, s = log2 zpg, which the general formula also reads correctly (the kernels that are not hot use it for both).
+inline uint32_t grouped_zpg_of(int Z, bool general = false)
 {
+    if (general) return static_cast<uint32_t>(std::max(1, (Z + kGroups - 1) / kGroups));
     uint32_t s = 0;
     while ((static_cast<int64_t>(kGroups) << s) < Z) ++s;
-    return s;
+    return 1u << s;
+}
+inline uint32_t grouped_gdiv_of(int Z, bool general = false)
+{
+    const uint32_t zpg = grouped_zpg_of(Z, general);
+    uint32_t sh = 0;
+    if (!general) {
+        while ((1u << sh) < zpg) ++sh;
+        return 1u | sh << 17 | (zpg - 1u) << 22;
+    }
+    sh = 1;
+    while ((1ull << sh) < static_cast<unsigned long long>(std::max(Z, 1)) * zpg) ++sh;
+    const uint32_t M = static_cast<uint32_t>(((1ull << sh) + zpg - 1) / zpg);
+    return M | sh << 17 | (zpg - 1u) << 22;
+}
+__host__ __device__ __forceinline__ uint32_t gdiv_zpg(uint32_t p) { return (p >> 22) + 1u; }
+__host__ __device__ __forceinline__ uint32_t gdiv_group(uint32_t p, uint32_t dest)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(dest, p & 0x1FFFFu) >> ((p >> 17) & 31u);
+#else
+    return static_cast<uint32_t>((static_cast<unsigned long long>(dest) * (p & 0x1FFFFu)) >> ((p >> 17) & 31u));
+#endif
+}
+// a driver's destination inside its group g (what the packed word carries above the car id)
+__host__ __device__ __forceinline__ uint32_t gdiv_local(uint32_t p, uint32_t dest, uint32_t g) { return dest - g * gdiv_zpg(p); }
+// GEN = false: the word describes power-of-two groups (a shift and a mask)
+template <bool GEN>
+__device__ __forceinline__ uint32_t gdiv_group_t(uint32_t p, uint32_t dest)
+{
+    if constexpr (GEN) return gdiv_group(p, dest);
+    else return dest >> ((p >> 17) & 31u);
+}
+template <bool GEN>
+__device__ __forceinline__ uint32_t gdiv_local_t(uint32_t p, uint32_t dest, uint32_t g)
+{
+    if constexpr (GEN) return gdiv_local(p, dest, g);
+    else return dest & (p >> 22);
 }
 
 // ------------------------------------------------------------------------------------------------ row packs
@@ -224,7 +270,7 @@ struct GroupedArgs {
     // (ids / cnt_a above) before its sampler workgroups read them; pchunks = chunks of origin zones to place (0: nothing pending)
     const uint32_t *pD, *pcntg;
     int pchunks;
-    uint32_t cap, scap, idbits, gshift, step;
+    uint32_t cap, scap, idbits, gdiv, step;   // (gdiv: the packed group divisor, grouped_gdiv_of)
     // (rare->parts == 1: a launch walks whole buckets in overflow rounds of BLOCK cars.  > 1: of a HEAVY bucket -- more than
     //  kHeavy * CPT * BLOCK cars -- that gets a place in rare->heavy_list it takes the first CPT * BLOCK cars only;
     //  k_grouped_sample_heavy, launched behind it with parts - 1 blocks per listed zone, takes the rest)
@@ -1051,7 +1097,7 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
                 // drivers: K rank atomics in flight together
                 uint32_t rank[K];
 #pragma unroll
-                for (int c = 0; c < K; ++c) rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+                for (int c = 0; c < K; ++c) rank[c] = drive[c] ? atomicAdd(&gb[gdiv_group_t<SPARSE>(a.gdiv, dest[c])], 1u) : 0u;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     if (valid[c] & !drive[c]) put32(stay_out, bS + static_cast<uint32_t>(__popcll(mS[c] & below)), id[c]);
@@ -1060,8 +1106,8 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     if (drive[c]) {
-                        const uint32_t g = dest[c] >> a.gshift;
-                        const uint32_t packed = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                        const uint32_t g = gdiv_group_t<SPARSE>(a.gdiv, dest[c]);
+                        const uint32_t packed = id[c] | (gdiv_local_t<SPARSE>(a.gdiv, dest[c], g) << a.idbits);
                         if (rank[c] < static_cast<uint32_t>(kStage)) stage[g * kStage + rank[c]] = packed;
                         else if (rank[c] < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank[c]], packed);
                     }
@@ -1163,9 +1209,9 @@ __device__ __forceinline__ void grouped_sample_body(const GroupedArgs &a, const 
             b1 = from_lane0(b1);
             if (valid1 & !drive1) stay_out[b1 + static_cast<uint32_t>(__popcll(m1 & below))] = idx;
             if (drive1) {
-                const uint32_t g = dest1[0] >> a.gshift;
+                const uint32_t g = gdiv_group_t<SPARSE>(a.gdiv, dest1[0]);
                 const uint32_t rank = atomicAdd(&gb[g], 1u);
-                const uint32_t packed = idx | ((dest1[0] & ((1u << a.gshift) - 1u)) << a.idbits);
+                const uint32_t packed = idx | (gdiv_local_t<SPARSE>(a.gdiv, dest1[0], g) << a.idbits);
                 if (rank < static_cast<uint32_t>(kStage)) stage[g * kStage + rank] = packed;
                 else if (rank < a.scap) hand_store<FUSED>(&runs[g * a.scap + rank], packed);
             }
@@ -1323,7 +1369,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
         uint32_t rank[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            rank[c] = drive[c] ? atomicAdd(&gb[dest[c] >> a.gshift], 1u) : 0u;
+            rank[c] = drive[c] ? atomicAdd(&gb[gdiv_group_t<SPARSE>(a.gdiv, dest[c])], 1u) : 0u;
             nd += drive[c] ? 1u : 0u;
         }
         for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o, 64);
@@ -1362,9 +1408,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_grouped_sample_heavy(GroupedArgs a
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             if (drive[c]) {
-                const uint32_t g = dest[c] >> a.gshift;
+                const uint32_t g = gdiv_group_t<SPARSE>(a.gdiv, dest[c]);
                 const uint32_t p = gbase[g] + rank[c];
-                if (p < a.scap) runs[g * a.scap + p] = id[c] | ((dest[c] & ((1u << a.gshift) - 1u)) << a.idbits);
+                if (p < a.scap) runs[g * a.scap + p] = id[c] | (gdiv_local_t<SPARSE>(a.gdiv, dest[c], g) << a.idbits);
             }
         }
     }
@@ -1852,7 +1898,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         __builtin_amdgcn_s_setprio(CPM_PLACE_PRIO);
 #endif
         grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true, false, PERM>(
-            g, j, u.p, dyn, a.D, a.cntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status,
+            g, j, u.p, dyn, a.D, a.cntg, static_cast<int>(gdiv_zpg(a.gdiv)), kFusedChunk, a.Z, a.cap, a.scap, a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status,
             a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit, nullptr, PERM ? a.perm_t : nullptr);
     }
 }
@@ -1880,11 +1926,11 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
         const int b = blockIdx.x;
         const int g = (b / (8 * a.pchunks)) * 8 + (b & 7), j = (b >> 3) % a.pchunks;
         grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, false, true>(
-            g, j, u.p, dyn, a.pD, a.pcntg, 1 << a.gshift, kFusedChunk, a.Z, a.cap, a.scap, a.idbits, const_cast<uint32_t *>(a.cnt_a),
+            g, j, u.p, dyn, a.pD, a.pcntg, static_cast<int>(gdiv_zpg(a.gdiv)), kFusedChunk, a.Z, a.cap, a.scap, a.idbits, const_cast<uint32_t *>(a.cnt_a),
             const_cast<uint32_t *>(a.ids), a.rare->status, nullptr, 0u, 0u, a.done_t + static_cast<size_t>(g) * kDoneStride);
     } else {
         // sampler block 8 q + x takes a zone of a group g with g % 8 == x: the XCD its arrivals were placed on (blockIdx % 8)
-        const int bs = blockIdx.x - npl, zpg = 1 << a.gshift;
+        const int bs = blockIdx.x - npl, zpg = static_cast<int>(gdiv_zpg(a.gdiv));
         const int g = (bs & 7) + 8 * ((bs >> 3) / zpg), z = g * zpg + ((bs >> 3) % zpg);
         if (g >= kGroups || z >= a.Z) return;
         grouped_sample_body<kFusedThreads, CPT, NQ, GROUPED, false, true, SPARSE>(a, z, dyn, u.s, nullptr, a.done_t + static_cast<size_t>(g) * kDoneStride,
@@ -1898,7 +1944,7 @@ struct PlaceShape {
 };
 inline PlaceShape place_shape(int Z)
 {
-    const int zpg = 1 << grouped_gshift_of(Z);
+    const int zpg = static_cast<int>(grouped_zpg_of(Z));
     PlaceShape p;
     p.pb = zpg <= 512 ? 512 : 1024;
     const int seg = p.pb / 16;
@@ -2130,7 +2176,7 @@ struct TravelArgs {
     uint32_t list_off;            // sparse rows: byte offset of the threads' driver lists in the block's LDS (behind the largest row)
     unsigned long long *tt_part;  // [kTravelParts] partial sums, zero between resamples
     size_t d_stride, c_stride;    // words between the runs / run lengths of consecutive hours (one launch for all hours), or 0
-    int t0, gshift;               // hour of blockIdx.y = 0
+    int t0, zpg;                  // hour of blockIdx.y = 0; zones per destination group
     uint32_t step0;               // its Philox step
     CarIndex cars;
     uint64_t seed;
@@ -2205,7 +2251,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
 #pragma unroll 2
             for (int u = 0; u < kTravelList; ++u) {
                 if (!live[u]) continue;
-                const uint32_t dest = (gq[u] << tr.gshift) + (w[u] >> idbits);
+                const uint32_t dest = gq[u] * static_cast<uint32_t>(tr.zpg) + (w[u] >> idbits);
                 if (dest == static_cast<uint32_t>(z)) {  // same zone: 300 s (src/resampling.jl:58-60)
                     tt += q16(300.0);
                 } else {
@@ -2244,7 +2290,7 @@ __global__ __launch_bounds__(256) void k_grouped_travel(const uint32_t *__restri
                 if (prefix[g + step] <= i) g += step;
             g = live[u] ? g : 0u;
             w[u] = live[u] ? D[(static_cast<size_t>(z) * kGroups + g) * scap + (i - prefix[g])] : 0u;
-            dest[u] = (g << tr.gshift) + (w[u] >> idbits);
+            dest[u] = g * static_cast<uint32_t>(tr.zpg) + (w[u] >> idbits);
         }
         double mean[kTravelBatch], sd[kTravelBatch];
 #pragma unroll
@@ -2372,7 +2418,7 @@ inline void grouped_launch_hour_nq(const GroupedArgs &a, hipStream_t stream)
 inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
 {
     const int need = (pack_row_words(Zq, G, smap) / 4 + kSampleBlock - 1) / kSampleBlock;
-    return (1 << grouped_gshift_of(Z)) <= kFusedZpg && need <= 12;
+    return static_cast<int>(grouped_zpg_of(Z)) <= kFusedZpg && need <= 12;
 }
 // ... and where it PAYS.  MEASURED (one launch against two per hour, 1,000 cars per zone, interleaved runs on one box, ms per
 // resample): Z = 1,536: 0.524 / 0.493, 2,357: 0.664 / 0.650, 3,072: 0.710 / 0.727, 4,096: 0.868 / 0.912 (500 cars per zone: 0.703 /
@@ -2427,7 +2473,7 @@ inline void grouped_launch_hour_pf_nq(const GroupedArgs &a, hipStream_t stream)
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    launch(k_grouped_hour_pf<CPT, NQ, GROUPED, SPARSE>, dim3(static_cast<unsigned>(a.pchunks * kGroups + (kGroups << a.gshift))), dim3(kFusedThreads), lds, stream, a);
+    launch(k_grouped_hour_pf<CPT, NQ, GROUPED, SPARSE>, dim3(static_cast<unsigned>(a.pchunks * kGroups + kGroups * static_cast<int>(gdiv_zpg(a.gdiv)))), dim3(kFusedThreads), lds, stream, a);
 }
 template <int CPT, bool GROUPED>
 inline void grouped_launch_hour_pf_c(const GroupedArgs &a, hipStream_t stream)
@@ -2605,9 +2651,13 @@ namespace cpm {
 // box 0.874 -> 0.851: the unpadded form also flipped between 0.86 and 0.89 from process to process, the padded one does not)
 inline uint32_t odd_lines(uint32_t words) { return ((words / 32u) & 1u) == 0u ? words + 32u : words; }
 inline uint32_t grouped_scap(uint32_t cap) { return odd_lines((std::max<uint32_t>(64u, cap / 4) + 31u) / 32u * 32u); }
-inline uint32_t grouped_gshift(int Z) { return grouped_gshift_of(Z); }
-// packed driver = id | (dest mod 2^gshift) << idbits
-inline uint32_t grouped_idbits(int Z) { return 32u - std::max(1u, grouped_gshift(Z)); }
+// packed driver = id | (dest - group * zpg) << idbits: the local destination takes ceil(log2 zpg) bits, at least one
+inline uint32_t grouped_idbits(int Z, bool general = false)
+{
+    uint32_t b = 1;
+    while ((1u << b) < grouped_zpg_of(Z, general)) ++b;
+    return 32u - b;
+}
 inline uint32_t grouped_cap(int64_t n, int Z, int cap_mult)
 {
     const int64_t mean = (n + Z - 1) / Z;
@@ -2621,7 +2671,7 @@ inline bool grouped_path_fits(int64_t n, int Z, int cap_mult = 4)
 {
     if (!pack_row_fits(Z) || n < 1 || n >= (int64_t(1) << 30)) return false;
     const uint32_t cap = grouped_cap(n, Z, cap_mult);
-    if (n > (int64_t(1) << grouped_idbits(Z)) || (1 << grouped_gshift(Z)) > kMaxZonesPerGroup) return false;
+    if (n > (int64_t(1) << grouped_idbits(Z)) || static_cast<int>(grouped_zpg_of(Z)) > kMaxZonesPerGroup) return false;
     if (!place_shape_fits(Z)) return false;
     const int64_t bytes = static_cast<int64_t>(Z) * cap * 4 * 3 + 2 * static_cast<int64_t>(Z) * kGroups * grouped_scap(cap) * 4;
     return bytes <= (int64_t(cap_mult <= 4 ? 24 : 80) << 30);
@@ -2634,7 +2684,7 @@ struct GroupedWork {
     int Z = 0, T = 0, nb0 = 0;
     int cap_mult = 4;        // bucket region = cap_mult x the mean bucket size; doubled by the context after an overflow (up to kMaxCapMult)
     int cap_mult_alloc = 0;  // what the arrays below were sized for
-    uint32_t cap = 0, scap = 0, idbits = 0, gshift = 0;
+    uint32_t cap = 0, scap = 0, idbits = 0, gdiv = 0, zpg = 1;
     uint32_t *ids0 = nullptr, *idsA = nullptr, *idsB = nullptr;  // [Z*cap]: cached initial bucketing, ping-pong
     uint32_t *cnt0 = nullptr;                                    // [2][Z] the cached initial buckets: stayers (all cars after bucketing) | arrivals
     uint32_t *cnt = nullptr;                                     // [T+1][2][Z] per hour: stayers | arrivals of every bucket; then [T][chunks] the fused hour's hand-off counters
@@ -2647,7 +2697,8 @@ struct GroupedWork {
     int day_mix = 1;                                             // its block order: placing blocks among the sampler workgroups (1) or in front of them (0)
     GroupedArgs *day_hours = nullptr;                            // [T] the hours' arguments of a day launch (device memory, filled by k_grouped_zero)
     uint32_t *perm = nullptr;                                    // [T][Z] the zones of every table hour, largest bucket first (k_zone_order, behind every IVP)
-    bool perm_valid = false, use_perm = false;                   // ... written at least once since the arrays were allocated; CPM_OPT_ZONE_ORDER
+    bool perm_valid = false;
+    int use_perm = 2;  // 0 zone order, 1 largest-first, 2 (default) largest-first for sparse row packs only                   // ... written at least once since the arrays were allocated; CPM_OPT_ZONE_ORDER
     int fused_lag = 1 << 20;                                     // chunks of sampler workgroups between a chunk and its placing blocks; >= all chunks (default):
                                                                  // every sampler workgroup first, then every placing block
     uint32_t fused_spin = kFusedSpinLimit;
@@ -2662,6 +2713,13 @@ struct GroupedWork {
     int hgrid = 0;                                               // zones the heavy launch covers
     const uint32_t *ivp_ids = nullptr, *ivp_cnt = nullptr;       // final buckets of the last IVP (grouped_commit_ivp)
 
+    // destination groups of a run: general (any zones per group) for sparse row packs, power-of-two for dense ones (grouped_gdiv_of)
+    void set_groups(bool general)
+    {
+        idbits = grouped_idbits(Z, general);
+        gdiv = grouped_gdiv_of(Z, general);
+        zpg = grouped_zpg_of(Z, general);
+    }
     // what the last run saw -> how the next one is launched: enough workgroups per zone for the largest bucket, at most 32
     void set_parts(uint32_t largest_heavy_bucket, uint32_t most_heavy_buckets)
     {
@@ -2727,8 +2785,8 @@ struct GroupedWork {
         cap_mult_alloc = cap_mult;
         cap = grouped_cap(n, Z, cap_mult);
         scap = grouped_scap(cap);
-        idbits = grouped_idbits(Z);
-        gshift = grouped_gshift(Z);
+        set_groups(false);
+
         nb0 = static_cast<int>(std::max<int64_t>({int64_t(1), std::min<int64_t>(2 * cu_count, (n + 4095) / 4096),
                                                   (n + int64_t(kBucketMaxPass) * 1024 - 1) / (int64_t(kBucketMaxPass) * 1024)}));
         hipError_t e = hipSuccess;
@@ -2816,6 +2874,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     const int Z = tb.Z, T = tb.T;
     hipError_t e = w.ensure(n, Z, T, cu_count);
     if (e != hipSuccess) return hip_fail(e, "grouped zone workspace");
+    w.set_groups(tb.smap != 0);
     const size_t lds_bins = sizeof(uint32_t) * static_cast<size_t>(Z);
     if (!w.attrs_set) {
         if (lds_bins > 48 * 1024)
@@ -2849,7 +2908,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.cap = w.cap;
         a.scap = w.scap;
         a.idbits = w.idbits;
-        a.gshift = w.gshift;
+        a.gdiv = w.gdiv;
         a.cars = cars;
         a.seed = seed;
         a.lag = w.fused_lag;
@@ -2861,7 +2920,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         a.perm_t = nullptr;
     };
     // zones dealt largest-first (k_grouped_hour<PERM>): a list exists (an IVP has run on these arrays) and the run array fits 32-bit offsets
-    const bool permute = w.use_perm && w.perm_valid && static_cast<uint64_t>(Z) * kGroups * w.scap * 4u < (1ull << 32);
+    const bool permute = (w.use_perm == 1 || (w.use_perm == 2 && tb.smap != 0)) && w.perm_valid && static_cast<uint64_t>(Z) * kGroups * w.scap * 4u < (1ull << 32);
     if (day_n >= 2) {
         std::memset(&day.base, 0, sizeof(day.base));
         hour_base(day.base);
@@ -2922,14 +2981,14 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
     auto flush_pending = [&]() {  // ... or for a placing launch of their own, when that launch is not of the placing-first kind
         if (!pend_D) return;
         prof_begin(CPM_PROFILE_PLACE);
-        grouped_launch_place(stream, pend_D, pend_cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, const_cast<uint32_t *>(cnt) + Z, const_cast<uint32_t *>(ids), status);
+        grouped_launch_place(stream, pend_D, pend_cntg, static_cast<int>(w.zpg), Z, w.cap, w.scap, w.idbits, const_cast<uint32_t *>(cnt) + Z, const_cast<uint32_t *>(ids), status);
         prof_end(CPM_PROFILE_PLACE);
         pend_D = pend_cntg = nullptr;
     };
     int t_first = 0;
     if (day_n >= 2) {
         prof_begin(CPM_PROFILE_SAMPLER);
-        grouped_launch_day(w.day_hours, day_n, Z, tb.Zq, G, tb.smap, static_cast<int>(w.gshift), nchunk, w.day_mix, mean, stream);
+        grouped_launch_day(w.day_hours, day_n, Z, tb.Zq, G, tb.smap, static_cast<int>(w.zpg), nchunk, w.day_mix, mean, stream);
         prof_end(CPM_PROFILE_SAMPLER);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "grouped zone day launch");
         // the drivers of its last hour are still in their runs: placed in front of hour T's sampler workgroups, or by a launch of their own
@@ -2992,7 +3051,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
                 pend_cntg = a.cntg;
             } else if (!fuse) {
                 prof_begin(CPM_PROFILE_PLACE);
-                grouped_launch_place(stream, a.D, a.cntg, 1 << w.gshift, Z, w.cap, w.scap, w.idbits, cnt_next + Z, ids_next, status);
+                grouped_launch_place(stream, a.D, a.cntg, static_cast<int>(w.zpg), Z, w.cap, w.scap, w.idbits, cnt_next + Z, ids_next, status);
                 prof_end(CPM_PROFILE_PLACE);
             }
             ids = ids_next;
@@ -3009,7 +3068,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
             tr.tt_part = w.tt_part;
             tr.d_stride = tr.c_stride = 0;
             tr.t0 = t;
-            tr.gshift = static_cast<int>(w.gshift);
+            tr.zpg = static_cast<int>(w.zpg);
             tr.step0 = step;
             tr.cars = cars;
             tr.seed = seed;
@@ -3033,7 +3092,7 @@ int32_t grouped_run(GroupedWork &w, hipStream_t stream, const GroupedTables &tb,
         tr.d_stride = w.run_words();
         tr.c_stride = w.len_words();
         tr.t0 = 0;
-        tr.gshift = static_cast<int>(w.gshift);
+        tr.zpg = static_cast<int>(w.zpg);
         tr.step0 = static_cast<uint32_t>(T - 1);
         tr.cars = cars;
         tr.seed = seed;

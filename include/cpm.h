@@ -83,8 +83,11 @@ extern "C" {
 #define CPM_OPT_FUSED_LAG 5     /* chunks of 64 sampler workgroups between a chunk and its placing blocks in the fused launch; at or above the number
                                    of chunks (the default): every sampler workgroup first, then every placing block */
 #define CPM_OPT_ZONE_ORDER 6    /* 1: the one-launch hour deals its sampler workgroups the zones LARGEST-FIRST (by their size at the same hour of the
-                                   last initial-value problem run in this context); 0 (default): zone order.  A scheduling hint: the counts do not
-                                   depend on it.  Measured 4 % SLOWER at 4,096 zones (profiles/round4_notes.md): kept as a tested option only */
+                                   last initial-value problem run in this context); 0: zone order; 2 (default): largest-first on sparse row packs
+                                   (datasets), zone order on dense ones.  A scheduling hint: the counts do not depend on it.  Measured (same box,
+                                   profiles/round4_notes.md): Melbourne-shaped tables, Z = 2,357 x 1,000 cars per zone 0.686 -> 0.587 ms per resample
+                                   (1.5 rounds of workgroups: the hour ended on whatever large bucket came last), x 500 0.443 -> 0.412; dense
+                                   4,096 zones 2-4 % SLOWER (zone order is also memory order of the packs and of the runs) */
 #define CPM_OPT_PROFILE_KERNEL 3 /* which hourly launch CPM_OPT_PROFILE brackets: */
 #define CPM_PROFILE_SAMPLER 0   /*   the sampler (default; every kernel family has one) */
 #define CPM_PROFILE_PLACE 1     /*   the grouped path's placing kernel */

@@ -20,7 +20,7 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--melbourne", action="store_true")
 ap.add_argument("--skew", type=int, default=0)
-ap.add_argument("--order", default="1", help="comma-separated CPM_OPT_ZONE_ORDER values to cross with the modes (1: zones largest-first, 0: zone order)")
+ap.add_argument("--order", default="2", help="comma-separated CPM_OPT_ZONE_ORDER values to cross with the modes (1: zones largest-first, 0: zone order)")
 args = ap.parse_args()
 Z, T, cpz = args.zones, 24, args.cpz
 C = Z * cpz

@@ -24,10 +24,7 @@ s.solve_ivp(0x5EEDCA125, want=False)
 s.set_fused(mode)
 L = _lib.load()
 L.cpm_diag_place_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-gshift = 0
-while (32 << gshift) < Z:
-    gshift += 1
-zpg, pc = 1 << gshift, (Z + 63) // 64
+zpg, pc = max(1, (Z + 31) // 32), (Z + 63) // 64   # (zones per destination group: grouped_zpg_of)
 per = 32 * (zpg + pc)
 nb = (T - 1) * per
 for _ in range(3):
