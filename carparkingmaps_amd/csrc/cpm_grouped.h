@@ -2429,7 +2429,9 @@ inline bool fused_shape_ok(int Z, int Zq, int G, int smap = 0)
 // ms per resample: 1,000 cars per zone 0.721 / 0.742, 100 cars per zone 0.331 / 0.322 -- one launch from ~500 cars per zone on.
 inline bool fused_pays(int Z, int Zq, int G, int cu_count, int smap = 0, int64_t mean = 0)
 {
-    if (smap) return mean >= 512 && Z >= 6 * std::max(cu_count, 1);
+    // (round 4, with the zones dealt largest-first and groups of any size: one launch / two launches per hour at Z = 2,357, Melbourne-shaped,
+    //  100 cars per zone 0.331 / 0.309, 200: 0.352 / 0.342, 300: 0.372 / 0.406, 400: 0.395 / 0.442, 500: 0.412 / 0.471 -- one launch from 256 on)
+    if (smap) return mean >= 256 && Z >= 6 * std::max(cu_count, 1);
     const size_t lds = fused_lds_bytes(Zq, G, smap) + 4608;  // (+ the static part: SampleLds / PlaceLds)
     return Z >= 12 * std::max(cu_count, 1) && 5 * lds <= 160 * 1024;
 }
