@@ -1534,7 +1534,7 @@ __device__ __noinline__ void place_surplus_out(PlaceLds<PB, KRUNS, ZPG> &pl, con
 #define CPM_PLACE_NEAR 4    // ... and once all but this many sampler workgroups of the chunk have handed over:
 #endif
 #ifndef CPM_PLACE_SLEEP_NEAR
-#define CPM_PLACE_SLEEP_NEAR 32
+#define CPM_PLACE_SLEEP_NEAR 4
 #endif
 constexpr uint32_t kFusedSpinLimit = 1u << 15;  // default number of polls: x (one L2 round trip + s_sleep 32) = tens of milliseconds
 // SIGNAL (placing first, k_grouped_hour_pf): the buckets this block fills are read by sampler workgroups of the SAME launch -- the
@@ -1547,7 +1547,7 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                                                    const uint32_t *__restrict__ cntg, int zpg, int zps, int Z, uint32_t cap, uint32_t scap, uint32_t idbits,
                                                    uint32_t *__restrict__ cnt_a_next, uint32_t *__restrict__ ids_next, unsigned long long *status,
                                                    const uint32_t *done_chunk, uint32_t need, uint32_t spin_limit, uint32_t *done_out = nullptr,
-                                                   const uint32_t *__restrict__ perm = nullptr)
+                                                   const uint32_t *__restrict__ perm = nullptr, const bool slow_poll = false)
 {
     // A run's first 32 entries are held by EIGHT lanes, four consecutive entries each: one 16-byte load per lane and run (two 4-byte
     // loads per lane with sixteen lanes per run before: 12 load instructions per thread instead of 4, and in the fused hour, where
@@ -1596,7 +1596,10 @@ __device__ __forceinline__ void grouped_place_body(const int g, const int j, Pla
                 // (~1 us between polls while the chunk is far from complete: 32 placing blocks poll each counter, and polling every 0.25 us
                 //  all along cost the Melbourne-shaped hour, whose placing blocks wait while samplers still run, 3.5 %; close to the end
                 //  a short interval takes ~1 us off the hand-over: -0.7 % at S4k)
+                //  (same box, interleaved: S4k 0.8126 -> 0.7967 ms per resample with 4 / 4; 16 / 4: 0.7994; 8 / 2: 0.8027; 4 / 1: as 4 / 4;
+                //   ~2 us while far: S4k +0.9 %, the Melbourne-shaped hour -2.5 % -- that is what slow_poll, the sparse instantiations, takes)
                 if (seen + CPM_PLACE_NEAR >= need) __builtin_amdgcn_s_sleep(CPM_PLACE_SLEEP_NEAR);
+                else if (slow_poll) __builtin_amdgcn_s_sleep(2 * CPM_PLACE_SLEEP);
                 else __builtin_amdgcn_s_sleep(CPM_PLACE_SLEEP);
             }
             if (tid == 0) pl.go = ok ? 1u : 0u;
@@ -1912,7 +1915,7 @@ __global__ __launch_bounds__(kFusedThreads, CPM_WPS) CPM_SGPR_ATTR void k_groupe
 #endif
         grouped_place_body<kFusedThreads, kFusedKruns, kFusedKdeep, kFusedZpg, true, false, PERM>(
             g, j, u.p, dyn, a.D, a.cntg, static_cast<int>(gdiv_zpg(a.gdiv)), kFusedChunk, a.Z, a.cap, a.scap, a.idbits, a.cnt_next + a.Z, a.ids_next, a.rare->status,
-            a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit, nullptr, PERM ? a.perm_t : nullptr);
+            a.done_t + static_cast<size_t>(j) * kDoneStride, need, a.spin_limit, nullptr, PERM ? a.perm_t : nullptr, SPARSE);
     }
 }
 
